@@ -1,0 +1,134 @@
+"""Batched FOM host API on torch device tensors (thin layer over the C ABI).
+
+``fom_run`` is the batched form of the reference's ``FEMBurgers.fom_burgers``
+(FEM/fem_burgers.py:646-707): B independent (mu1, mu2) samples, one wavefront each.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+@dataclass
+class FomResult:
+    hist: torch.Tensor     # (B, nsteps+1, N) float64, time-major per sample
+    iters: torch.Tensor    # (B, nsteps) int32, Picard iterations per step
+    flags: torch.Tensor    # (B,) int32, BG_FLAG_* bits
+
+    def snapshots(self):
+        """(B, N, nsteps+1) C-contiguous: the reference's per-sample (N, nT+1) layout."""
+        return transpose_batched(self.hist)
+
+    @property
+    def newton_steps(self):
+        return int(self.iters.sum().item())
+
+
+def _as_dev(a, device, shape=None):
+    t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64))
+    t = t.to(device=device, dtype=torch.float64)
+    if shape is not None:
+        t = t.expand(shape)
+    return t.contiguous()
+
+
+def check_mesh(X):
+    Xh = X.detach().cpu().numpy() if isinstance(X, torch.Tensor) else np.asarray(X, dtype=np.float64)
+    if Xh.ndim != 1 or len(Xh) < 2:
+        raise ValueError("X must be a 1-D array of at least 2 nodes")
+    if not _lib.mesh_is_uniform(Xh):
+        raise NotImplementedError("the HIP kernels cover uniform meshes (np.linspace) only")
+    return Xh
+
+
+def fom_run(X, u0, mu1, mu2, dt, nsteps, E=0.0, tol=1e-6, max_it=20, supg=True, device=None,
+            out=None, validate_mesh=True):
+    """Run B samples through ``nsteps`` implicit-Euler steps on the current HIP stream.
+
+    X (N,), u0 (N,) or (B, N), mu1/mu2 scalar or (B,).  Returns a :class:`FomResult` of
+    device tensors; nothing is synchronised.
+    """
+    L = _lib.load()
+    device = _lib.require_device(device)
+    if validate_mesh:
+        check_mesh(X)
+    Xd = _as_dev(X, device)
+    N = Xd.numel()
+    mu1d = _as_dev(mu1, device).reshape(-1)
+    mu2d = _as_dev(mu2, device).reshape(-1)
+    B = max(mu1d.numel(), mu2d.numel())
+    mu1d = mu1d.expand(B).contiguous()
+    mu2d = mu2d.expand(B).contiguous()
+    u0d = _as_dev(u0, device)
+    if u0d.dim() == 1:
+        u0d = u0d.unsqueeze(0)
+    if u0d.shape[-1] != N:
+        raise ValueError(f"u0 has {u0d.shape[-1]} entries per sample, mesh has {N}")
+    u0d = u0d.expand(B, N).contiguous()
+    if out is None:
+        hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
+        iters = torch.empty((B, nsteps), dtype=torch.int32, device=device)
+        flags = torch.empty((B,), dtype=torch.int32, device=device)
+    else:
+        hist, iters, flags = out.hist, out.iters, out.flags
+    with torch.cuda.device(device):
+        rc = L.bg_fom_run(N, B, int(nsteps), _lib.ptr(Xd), _lib.ptr(u0d), _lib.ptr(mu1d), _lib.ptr(mu2d),
+                          float(dt), float(E), float(tol), int(max_it), 1 if supg else 0,
+                          _lib.ptr(hist), _lib.ptr(iters), _lib.ptr(flags), _lib.stream_ptr(device))
+    _lib.check(rc, "bg_fom_run")
+    return FomResult(hist, iters, flags)
+
+
+def fom_assemble(X, uk, un, mu1, mu2, dt, E=0.0, supg=True, device=None):
+    """One Picard assembly: returns (lo, di, up, rhs), each (B, N); rhs = b - A(uk) uk."""
+    L = _lib.load()
+    device = _lib.require_device(device)
+    check_mesh(X)
+    Xd = _as_dev(X, device)
+    N = Xd.numel()
+    ukd = _as_dev(uk, device).reshape(-1, N)
+    B = ukd.shape[0]
+    und = _as_dev(un, device).reshape(-1, N).expand(B, N).contiguous()
+    mu1d = _as_dev(mu1, device).reshape(-1).expand(B).contiguous()
+    mu2d = _as_dev(mu2, device).reshape(-1).expand(B).contiguous()
+    outs = [torch.empty((B, N), dtype=torch.float64, device=device) for _ in range(4)]
+    with torch.cuda.device(device):
+        rc = L.bg_fom_assemble(N, B, _lib.ptr(Xd), _lib.ptr(ukd), _lib.ptr(und), _lib.ptr(mu1d),
+                               _lib.ptr(mu2d), float(dt), float(E), 1 if supg else 0,
+                               *[_lib.ptr(o) for o in outs], _lib.stream_ptr(device))
+    _lib.check(rc, "bg_fom_assemble")
+    return tuple(outs)
+
+
+def tridiag_solve(lo, di, up, rhs):
+    """Batched tridiagonal solve, one wavefront per system; inputs (B, N) device tensors."""
+    L = _lib.load()
+    device = _lib.require_device(lo.device)
+    lo, di, up, rhs = [t.to(torch.float64).contiguous() for t in (lo, di, up, rhs)]
+    B, N = lo.shape
+    sol = torch.empty_like(rhs)
+    with torch.cuda.device(device):
+        rc = L.bg_tridiag_solve(N, B, _lib.ptr(lo), _lib.ptr(di), _lib.ptr(up), _lib.ptr(rhs),
+                                _lib.ptr(sol), _lib.stream_ptr(device))
+    _lib.check(rc, "bg_tridiag_solve")
+    return sol
+
+
+def transpose_batched(t):
+    """(B, R, C) -> (B, C, R), contiguous, by the HIP transpose kernel."""
+    L = _lib.load()
+    device = _lib.require_device(t.device)
+    t = t.contiguous()
+    B, R, C = t.shape
+    out = torch.empty((B, C, R), dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        for b0 in range(0, B, 32768):
+            b1 = min(B, b0 + 32768)
+            rc = L.bg_transpose_batched(b1 - b0, R, C, _lib.ptr(t[b0:b1]), _lib.ptr(out[b0:b1]),
+                                        _lib.stream_ptr(device))
+            _lib.check(rc, "bg_transpose_batched")
+    return out

@@ -1,0 +1,119 @@
+"""ctypes binding of libburgers_hip.so (the C ABI declared in include/burgers_hip.h).
+
+There is no CPU fallback: if the shared object is missing, or a call is made without a
+HIP device, this module raises.  torch is imported first so that the process uses one
+HIP runtime (torch's) for device memory, streams and our kernels alike.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+import torch  # noqa: F401  (must precede the CDLL load: one libamdhip64 per process)
+
+from . import build as _build
+
+c_double_p = ctypes.c_void_p      # raw device pointers travel as integers
+c_int_p = ctypes.c_void_p
+
+BG_OK = 0
+BG_ERR_BAD_ARG = -1
+BG_ERR_UNSUPPORTED_N = -2
+BG_ERR_NONUNIFORM = -3
+BG_ERR_LAUNCH = -4
+BG_ERR_UNSUPPORTED_R = -5
+BG_ERR_PROJECTION = -6
+BG_ERR_WORKSPACE = -7
+BG_PROJ_GALERKIN, BG_PROJ_LSPG = 0, 1
+BG_FLAG_HIT_CAP, BG_FLAG_NONFINITE = 1, 2
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "bg_abi_version": (ctypes.c_int, []),
+    "bg_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "bg_last_hip_error": (ctypes.c_int, []),
+    "bg_fom_max_n": (ctypes.c_int, []),
+    "bg_fom_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                  c_double_p, c_double_p, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_double, ctypes.c_int, ctypes.c_int, c_double_p, c_int_p,
+                                  c_int_p, ctypes.c_void_p]),
+    "bg_fom_assemble": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                       c_double_p, c_double_p, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
+                                       ctypes.c_void_p]),
+    "bg_tridiag_solve": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                        c_double_p, c_double_p, ctypes.c_void_p]),
+    "bg_transpose_batched": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
+                                            c_double_p, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+class BurgersHipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = _lib.bg_strerror(code).decode() if _lib is not None else str(code)
+        extra = f" (hipError {_lib.bg_last_hip_error()})" if code == BG_ERR_LAUNCH and _lib else ""
+        super().__init__(f"{where}: {msg}{extra} [code {code}]")
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load(build_if_missing=False):
+    """Load the shared object and bind every declared symbol.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        if build_if_missing:
+            _build.build_library()
+        else:
+            raise ImportError(
+                f"{path} is missing: build it with `python __graft_entry__.py build` "
+                "(there is no CPU fallback for the HIP path)")
+    L = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if L.bg_abi_version() != 1:
+        raise ImportError(f"ABI mismatch: library reports {L.bg_abi_version()}, binding expects 1")
+    _lib = L
+    return L
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(code, where):
+    if code != BG_OK:
+        raise BurgersHipError(code, where)
+
+
+def require_device(device=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: the Burgers HIP kernels need an MI355X (no CPU fallback)")
+    return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def mesh_is_uniform(X, rtol=1e-9):
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim != 1 or len(X) < 2:
+        return False
+    d = np.diff(X)
+    h = (X[-1] - X[0]) / (len(X) - 1)
+    return bool(h > 0 and np.all(np.abs(d - h) <= rtol * abs(h)))

@@ -1,0 +1,313 @@
+// fom.hip -- fused batched FOM time-stepper for gfx950 and its C-ABI entry points.
+//
+// Replaces the body of FEMBurgers.fom_burgers (reference FEM/fem_burgers.py:646-707):
+// one wavefront integrates one (mu1, mu2) sample through all time steps and all Picard
+// iterations; the state never leaves registers between iterations, HBM sees one
+// coalesced row write per time step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/burgers_hip.h"
+#include "fom_device.hpp"
+
+namespace {
+
+using namespace bg;
+
+thread_local int g_last_hip_error = 0;
+
+struct FomArgs {
+    const double* x;
+    const double* u0;
+    const double* mu1;
+    const double* mu2;
+    double* hist;
+    int32_t* iters;
+    int32_t* flags;
+    double dt, E, tol2;
+    int N, B, nsteps, max_it, supg;
+};
+
+constexpr int WAVES_PER_WG = 4;
+
+template <int R>
+__device__ __forceinline__ void load_rows(const double* __restrict__ src, int N, int row0, bool full,
+                                          double (&u)[R])
+{
+#pragma unroll
+    for (int j = 0; j < R; ++j) u[j] = (full || row0 + j < N) ? src[row0 + j] : 0.0;
+}
+
+template <int R>
+__device__ __forceinline__ void store_rows(double* __restrict__ dst, int N, int row0, bool full,
+                                           const double (&u)[R])
+{
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+        if (full || row0 + j < N) dst[row0 + j] = u[j];
+}
+
+template <int R, bool FULL>
+__global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void fom_fused_kernel(FomArgs a)
+{
+    const int lane = lane_id();
+    const int s = blockIdx.x * WAVES_PER_WG + (int)(threadIdx.x >> 6);
+    if (s >= a.B) return;                                   // wave-uniform
+    const int N = a.N;
+    const int row0 = lane * R;
+    const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
+    const MeshConst c = make_mesh_const(h, a.dt, a.E, a.supg);
+    const double mu1 = a.mu1[s], mu2 = a.mu2[s];
+
+    double hfs[R], fdt[R], u[R], g[R];
+    forcing_setup<R>(a.x, N, row0, mu2, c.h, a.dt, hfs, fdt);
+
+    double* hist = a.hist + (size_t)s * (size_t)(a.nsteps + 1) * (size_t)N;
+    load_rows<R>(a.u0 + (size_t)s * N, N, row0, FULL, u);
+    store_rows<R>(hist, N, row0, FULL, u);
+
+    int flags = 0;
+    for (int step = 0; step < a.nsteps; ++step) {
+        mass_rhs<R, FULL>(c, N, row0, u, fdt, g);
+        int k = 0;
+        bool more;
+        do {
+            double lo[R], di[R], up[R], rhs[R];
+            assemble<R, FULL>(c, N, row0, mu1, u, g, hfs, lo, di, up, rhs);
+            tridiag_solve<R>(lo, di, up, rhs);
+            double nd = 0.0, nu = 0.0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                u[j] += rhs[j];
+                nd = __builtin_fma(rhs[j], rhs[j], nd);
+                nu = __builtin_fma(u[j], u[j], nu);
+            }
+            nd = wave_sum(nd);
+            nu = wave_sum(nu);
+            ++k;
+            // reference: error = ||dU|| / ||U1||; continue while error > tol and k < cap.
+            // NaN compares false and ends the loop, as in the reference.
+            more = (nd > a.tol2 * nu) && (k < a.max_it);
+            if (!(nd - nd == 0.0) || !(nu - nu == 0.0)) flags |= BG_FLAG_NONFINITE;
+        } while (more);
+        if (k >= a.max_it) flags |= BG_FLAG_HIT_CAP;
+        store_rows<R>(hist + (size_t)(step + 1) * N, N, row0, FULL, u);
+        if (lane == 0) a.iters[(size_t)s * a.nsteps + step] = k;
+    }
+    if (lane == 0) a.flags[s] = flags;
+}
+
+// ---- diagnostics kernels: one assembly / one solve ---------------------------------
+struct AsmArgs {
+    const double *x, *uk, *un, *mu1, *mu2;
+    double *lo, *di, *up, *rhs;
+    double dt, E;
+    int N, B, supg;
+};
+
+template <int R, bool FULL>
+__global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void fom_assemble_kernel(AsmArgs a)
+{
+    const int lane = lane_id();
+    const int s = blockIdx.x * WAVES_PER_WG + (int)(threadIdx.x >> 6);
+    if (s >= a.B) return;
+    const int N = a.N, row0 = lane * R;
+    const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
+    const MeshConst c = make_mesh_const(h, a.dt, a.E, a.supg);
+    double hfs[R], fdt[R], u[R], un[R], g[R], lo[R], di[R], up[R], rhs[R];
+    forcing_setup<R>(a.x, N, row0, a.mu2[s], c.h, a.dt, hfs, fdt);
+    load_rows<R>(a.un + (size_t)s * N, N, row0, FULL, un);
+    load_rows<R>(a.uk + (size_t)s * N, N, row0, FULL, u);
+    mass_rhs<R, FULL>(c, N, row0, un, fdt, g);
+    assemble<R, FULL>(c, N, row0, a.mu1[s], u, g, hfs, lo, di, up, rhs);
+    store_rows<R>(a.lo + (size_t)s * N, N, row0, FULL, lo);
+    store_rows<R>(a.di + (size_t)s * N, N, row0, FULL, di);
+    store_rows<R>(a.up + (size_t)s * N, N, row0, FULL, up);
+    store_rows<R>(a.rhs + (size_t)s * N, N, row0, FULL, rhs);
+}
+
+struct SolveArgs {
+    const double *lo, *di, *up, *rhs;
+    double* sol;
+    int N, B;
+};
+
+template <int R>
+__global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void tridiag_solve_kernel(SolveArgs a)
+{
+    const int lane = lane_id();
+    const int s = blockIdx.x * WAVES_PER_WG + (int)(threadIdx.x >> 6);
+    if (s >= a.B) return;
+    const int N = a.N, row0 = lane * R;
+    double lo[R], di[R], up[R], rhs[R];
+    const size_t off = (size_t)s * N;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const bool in = row0 + j < N;
+        lo[j] = in ? a.lo[off + row0 + j] : 0.0;
+        di[j] = in ? a.di[off + row0 + j] : 1.0;
+        up[j] = in ? a.up[off + row0 + j] : 0.0;
+        rhs[j] = in ? a.rhs[off + row0 + j] : 0.0;
+    }
+    tridiag_solve<R>(lo, di, up, rhs);
+    store_rows<R>(a.sol + off, N, row0, false, rhs);
+}
+
+// ---- batched transpose out[b][c][r] = in[b][r][c] ----------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in,
+                                                        double* __restrict__ out, int rows, int cols)
+{
+    __shared__ double tile[32][33];
+    const size_t base = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        int r = r0 + ty + k, cc = c0 + tx;
+        if (r < rows && cc < cols) tile[ty + k][tx] = in[base + (size_t)r * cols + cc];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        int cc = c0 + ty + k, r = r0 + tx;
+        if (r < rows && cc < cols) out[base + (size_t)cc * rows + r] = tile[tx][ty + k];
+    }
+}
+
+// ---- dispatch ------------------------------------------------------------------------
+constexpr int kRowsPerLane[] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 16};
+
+int rows_per_lane(int N)
+{
+    for (int r : kRowsPerLane)
+        if (N <= 64 * r) return r;
+    return 0;
+}
+
+int check_launch()
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return BG_ERR_LAUNCH;
+    }
+    return BG_OK;
+}
+
+template <typename F>
+int dispatch_r(int N, F&& f)
+{
+    switch (rows_per_lane(N)) {
+        case 1: return f(std::integral_constant<int, 1>{});
+        case 2: return f(std::integral_constant<int, 2>{});
+        case 3: return f(std::integral_constant<int, 3>{});
+        case 4: return f(std::integral_constant<int, 4>{});
+        case 5: return f(std::integral_constant<int, 5>{});
+        case 6: return f(std::integral_constant<int, 6>{});
+        case 8: return f(std::integral_constant<int, 8>{});
+        case 9: return f(std::integral_constant<int, 9>{});
+        case 10: return f(std::integral_constant<int, 10>{});
+        case 12: return f(std::integral_constant<int, 12>{});
+        case 16: return f(std::integral_constant<int, 16>{});
+        default: return BG_ERR_UNSUPPORTED_N;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bg_abi_version(void) { return BG_ABI_VERSION; }
+
+int bg_last_hip_error(void) { return g_last_hip_error; }
+
+int bg_fom_max_n(void) { return 64 * 16; }
+
+const char* bg_strerror(int code)
+{
+    switch (code) {
+        case BG_OK: return "ok";
+        case BG_ERR_BAD_ARG: return "bad argument";
+        case BG_ERR_UNSUPPORTED_N: return "N not supported by the wave-per-sample kernels (2 <= N <= 1024)";
+        case BG_ERR_NONUNIFORM: return "mesh is not uniform";
+        case BG_ERR_LAUNCH: return "kernel launch failed (see bg_last_hip_error)";
+        case BG_ERR_UNSUPPORTED_R: return "reduced dimension not supported";
+        case BG_ERR_PROJECTION: return "unknown projection";
+        case BG_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}
+
+int bg_fom_run(int N, int B, int nsteps, const double* x, const double* u0, const double* mu1,
+               const double* mu2, double dt, double E, double tol, int max_it, int supg, double* hist,
+               int32_t* iters, int32_t* flags, void* stream)
+{
+    if (N < 2 || B < 0 || nsteps < 0 || max_it < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
+    if (B == 0) return BG_OK;
+    if (!x || !u0 || !mu1 || !mu2 || !hist || !flags || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
+    FomArgs a;
+    a.x = x; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
+    a.dt = dt; a.E = E; a.tol2 = tol * tol;
+    a.N = N; a.B = B; a.nsteps = nsteps; a.max_it = max_it; a.supg = supg;
+    const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_r(N, [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        if (N == 64 * R)
+            hipLaunchKernelGGL((fom_fused_kernel<R, true>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((fom_fused_kernel<R, false>), grid, block, 0, st, a);
+        return check_launch();
+    });
+}
+
+int bg_fom_assemble(int N, int B, const double* x, const double* uk, const double* un, const double* mu1,
+                    const double* mu2, double dt, double E, int supg, double* lo, double* di, double* up,
+                    double* rhs, void* stream)
+{
+    if (N < 2 || B < 0 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
+    if (B == 0) return BG_OK;
+    if (!x || !uk || !un || !mu1 || !mu2 || !lo || !di || !up || !rhs) return BG_ERR_BAD_ARG;
+    AsmArgs a;
+    a.x = x; a.uk = uk; a.un = un; a.mu1 = mu1; a.mu2 = mu2; a.lo = lo; a.di = di; a.up = up; a.rhs = rhs;
+    a.dt = dt; a.E = E; a.N = N; a.B = B; a.supg = supg;
+    const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_r(N, [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        if (N == 64 * R)
+            hipLaunchKernelGGL((fom_assemble_kernel<R, true>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((fom_assemble_kernel<R, false>), grid, block, 0, st, a);
+        return check_launch();
+    });
+}
+
+int bg_tridiag_solve(int N, int B, const double* lo, const double* di, const double* up, const double* rhs,
+                     double* sol, void* stream)
+{
+    if (N < 1 || B < 0) return BG_ERR_BAD_ARG;
+    if (B == 0) return BG_OK;
+    if (!lo || !di || !up || !rhs || !sol) return BG_ERR_BAD_ARG;
+    SolveArgs a{lo, di, up, rhs, sol, N, B};
+    const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_r(N, [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        hipLaunchKernelGGL((tridiag_solve_kernel<R>), grid, block, 0, st, a);
+        return check_launch();
+    });
+}
+
+int bg_transpose_batched(int B, int rows, int cols, const double* in, double* out, void* stream)
+{
+    if (B < 0 || rows < 0 || cols < 0) return BG_ERR_BAD_ARG;
+    if (B == 0 || rows == 0 || cols == 0) return BG_OK;
+    if (!in || !out || B > 65535) return BG_ERR_BAD_ARG;
+    const dim3 grid((cols + 31) / 32, (rows + 31) / 32, B), block(256);
+    hipLaunchKernelGGL(transpose_kernel, grid, block, 0, (hipStream_t)stream, in, out, rows, cols);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,240 @@
+// fom_device.hpp -- per-wavefront building blocks of the Burgers FOM Picard iteration.
+//
+// Row distribution: lane p of the wave owns the R consecutive mesh rows
+// [p*R, p*R+R), so N <= 64*R rows fit one wavefront; rows >= N are identity rows.
+// All per-row state lives in registers (fully unrolled, compile-time R).
+//
+// Arithmetic restated from the reference (FEM/fem_burgers.py), closed form for
+// 2-node elements on a uniform mesh:
+//   convection  :389-425   c1 = (2ul+ur)/6, c2 = (ul+2ur)/6
+//   forcing     :427-461   2-pt Gauss of 0.02*exp(mu2 x)
+//   SUPG        :500-581   s_e = tau*(ubar*du - (f1+f2)/2), tau = 0.5h/(2 max(|ubar|,1e-10))
+//   system      :676-689   A = M + dt C + dt E K, row 0 <- e0, b = M u^n + dt F - dt S, b0 = mu1
+#pragma once
+#include "wave_ops.hpp"
+
+namespace bg {
+
+constexpr double GP_A = 0.78867513459481287;  // (1 + 1/sqrt(3)) / 2
+constexpr double GP_B = 0.21132486540518713;  // (1 - 1/sqrt(3)) / 2
+
+struct MeshConst {
+    double h;      // uniform element length
+    double aoff;   // h/6 - dt*E/h     (off-diagonal base)
+    double dd2;    // 2*(h/3 + dt*E/h) (interior diagonal base)
+    double dd1;    // h/3 + dt*E/h     (last-row diagonal base)
+    double dt6;    // dt/6
+    double kap;    // 0.25*dt  (0 when SUPG is off)
+    double h6;     // h/6
+};
+
+__device__ __forceinline__ MeshConst make_mesh_const(double h, double dt, double E, int supg)
+{
+    MeshConst c;
+    c.h = h;
+    double eh = dt * E / h;
+    c.aoff = h / 6.0 - eh;
+    c.dd1 = h / 3.0 + eh;
+    c.dd2 = 2.0 * c.dd1;
+    c.dt6 = dt / 6.0;
+    c.kap = supg ? 0.25 * dt : 0.0;
+    c.h6 = h / 6.0;
+    return c;
+}
+
+// Per-sample constants: hfs[j] = h*(f(gp1)+f(gp2)) of the element to the right of local
+// row j, and fdt[j] = dt*F_i of row i = row0+j.
+template <int R>
+__device__ __forceinline__ void forcing_setup(const double* __restrict__ x, int N, int row0, double mu2,
+                                              double h, double dt, double (&hfs)[R], double (&fdt)[R])
+{
+    double frPrev = 0.0;   // right-node load of element row0-1
+    {
+        int e = row0 - 1;
+        if (e >= 0 && e < N - 1) {
+            double xl = x[e], xr = x[e + 1];
+            double f1 = 0.02 * exp(mu2 * (GP_A * xl + GP_B * xr));
+            double f2 = 0.02 * exp(mu2 * (GP_B * xl + GP_A * xr));
+            frPrev = (f1 * GP_B + f2 * GP_A) * (0.5 * h);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        int e = row0 + j;
+        double fl = 0.0, fr = 0.0, fs = 0.0;
+        if (e < N - 1) {
+            double xl = x[e], xr = x[e + 1];
+            double f1 = 0.02 * exp(mu2 * (GP_A * xl + GP_B * xr));
+            double f2 = 0.02 * exp(mu2 * (GP_B * xl + GP_A * xr));
+            fl = (f1 * GP_A + f2 * GP_B) * (0.5 * h);
+            fr = (f1 * GP_B + f2 * GP_A) * (0.5 * h);
+            fs = f1 + f2;
+        }
+        hfs[j] = h * fs;
+        fdt[j] = (e < N) ? dt * (frPrev + fl) : 0.0;
+        frPrev = fr;
+    }
+}
+
+// g = M u^n + dt F  (constant over the Picard iterations of one time step)
+template <int R, bool FULL>
+__device__ __forceinline__ void mass_rhs(const MeshConst& c, int N, int row0, const double (&u)[R],
+                                         const double (&fdt)[R], double (&g)[R])
+{
+    const double uL = from_lane_below(u[R - 1]);
+    const double uR = from_lane_above(u[0]);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const double um = (j == 0) ? uL : u[j - 1];
+        const double up = (j == R - 1) ? uR : u[j + 1];
+        const int i = row0 + j;
+        double inner = __builtin_fma(4.0, u[j], um) + up;
+        double last = __builtin_fma(2.0, u[j], um);
+        double v = __builtin_fma(c.h6, (i == N - 1) ? last : inner, fdt[j]);
+        g[j] = (!FULL && i >= N) ? 0.0 : v;
+    }
+}
+
+// One assembly: diagonals lo/di/up of A(u) and rhs = b - A u  (= -R of the reference).
+template <int R, bool FULL>
+__device__ __forceinline__ void assemble(const MeshConst& c, int N, int row0, double mu1,
+                                         const double (&u)[R], const double (&g)[R],
+                                         const double (&hfs)[R], double (&lo)[R], double (&di)[R],
+                                         double (&up)[R], double (&rhs)[R])
+{
+    const int lane = lane_id();
+    const double uL = from_lane_below(u[R - 1]);
+    const double uR = from_lane_above(u[0]);
+    double se[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const double ur = (j == R - 1) ? uR : u[j + 1];
+        const double w = u[j] + ur;
+        const double dif = ur - u[j];
+        up[j] = __builtin_fma(c.dt6, w + u[j], c.aoff);
+        if (j + 1 < R) lo[j + 1] = __builtin_fma(-c.dt6, w + ur, c.aoff);
+        const double mx = fmax(fabs(w), 2.0e-10);
+        const double t = __builtin_fma(w, dif, -hfs[j]);
+        se[j] = t * rcp(mx);
+    }
+    lo[0] = __builtin_fma(-c.dt6, __builtin_fma(2.0, u[0], uL), c.aoff);
+    const double seL = from_lane_below(se[R - 1]);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const double um = (j == 0) ? uL : u[j - 1];
+        const double ur = (j == R - 1) ? uR : u[j + 1];
+        const double sm = (j == 0) ? seL : se[j - 1];
+        const int i = row0 + j;
+        double d = __builtin_fma(c.dt6, um - ur, c.dd2);
+        double b = __builtin_fma(-c.kap, sm, g[j]);
+        double bb = __builtin_fma(c.kap, se[j], b);
+        double l = lo[j], p = up[j];
+        // special rows: last real row has no right element; rows >= N are identity
+        const bool is_last = FULL ? (j == R - 1 && lane == 63) : (i == N - 1);
+        if (FULL ? (j == R - 1) : true) {
+            double dl = __builtin_fma(c.dt6, __builtin_fma(2.0, u[j], um), c.dd1);
+            d = is_last ? dl : d;
+            p = is_last ? 0.0 : p;
+            bb = is_last ? b : bb;
+        }
+        if (!FULL) {
+            const bool pad = i >= N;
+            d = pad ? 1.0 : d;
+            p = pad ? 0.0 : p;
+            l = pad ? 0.0 : l;
+            bb = pad ? 0.0 : bb;   // u is 0 on padded rows, so rhs becomes 0
+        }
+        if (j == 0) {           // Dirichlet row (global row 0)
+            const bool first = lane == 0;
+            d = first ? 1.0 : d;
+            p = first ? 0.0 : p;
+            l = first ? 0.0 : l;
+            bb = first ? mu1 : bb;
+        }
+        double r = __builtin_fma(-l, um, bb);
+        r = __builtin_fma(-d, u[j], r);
+        r = __builtin_fma(-p, ur, r);
+        lo[j] = l; di[j] = d; up[j] = p; rhs[j] = r;
+    }
+}
+
+// Pivot-free tridiagonal solve across the wave (Wang partition + PCR on the 64
+// interface unknowns).  In: lo/di/up/rhs.  Out: solution in rhs.  lo, di are clobbered.
+template <int R>
+__device__ __forceinline__ void tridiag_solve(double (&lo)[R], double (&di)[R], const double (&up)[R],
+                                              double (&rhs)[R])
+{
+    const int lane = lane_id();
+    double A, C, D;           // normalised interface equation: A x[p-1] + x[p] + C x[p+1] = D
+    double gs[R > 1 ? R : 1];
+    if constexpr (R == 1) {
+        const double rb = rcp(di[0]);
+        A = lo[0] * rb; C = up[0] * rb; D = rhs[0] * rb;
+    } else {
+        // phase 1: eliminate sub-diagonal downwards; lo[] becomes the left spike f[],
+        // di[] becomes 1/pivot
+        double dp = di[0];
+        di[0] = rcp(dp);
+#pragma unroll
+        for (int j = 1; j < R; ++j) {
+            const double m = lo[j] * di[j - 1];
+            dp = __builtin_fma(-m, up[j - 1], di[j]);
+            di[j] = rcp(dp);
+            rhs[j] = __builtin_fma(-m, rhs[j - 1], rhs[j]);
+            lo[j] = -m * lo[j - 1];
+        }
+        // phase 2: eliminate super-diagonal upwards from row R-3; gs[] is the right spike
+        gs[R - 2] = up[R - 2];
+#pragma unroll
+        for (int j = R - 3; j >= 0; --j) {
+            const double t = up[j] * di[j + 1];
+            rhs[j] = __builtin_fma(-t, rhs[j + 1], rhs[j]);
+            lo[j] = __builtin_fma(-t, lo[j + 1], lo[j]);
+            gs[j] = -t * gs[j + 1];
+        }
+        // interface equation of this lane's last row, closed with the next lane's row 0
+        const double F0 = from_lane_above(lo[0] * di[0]);
+        const double G0 = from_lane_above(gs[0] * di[0]);
+        const double R0 = from_lane_above(rhs[0] * di[0]);
+        const double ul = up[R - 1];
+        const double B = __builtin_fma(-ul, F0, dp);
+        const double rb = rcp(B);
+        A = lo[R - 1] * rb;
+        C = -(ul * G0) * rb;
+        D = __builtin_fma(-ul, R0, rhs[R - 1]) * rb;
+    }
+    // PCR over the 64 interface equations; neighbours wrap mod 64, which is exact
+    // because A == 0 on lanes < stride and C == 0 on lanes >= 64 - stride.
+#pragma unroll
+    for (int s = 1; s < 64; s *= 2) {
+        const int below = ((lane - s) & 63) << 2, above = ((lane + s) & 63) << 2;
+        const double Dm = from_lane_rot(D, below), Dp = from_lane_rot(D, above);
+        const double Cm = from_lane_rot(C, below), Ap = from_lane_rot(A, above);
+        double Bn = __builtin_fma(-Cm, A, 1.0);
+        Bn = __builtin_fma(-Ap, C, Bn);
+        double Dn = __builtin_fma(-Dm, A, D);
+        Dn = __builtin_fma(-Dp, C, Dn);
+        const double rb = rcp(Bn);
+        D = Dn * rb;
+        if (s < 32) {
+            const double Am = from_lane_rot(A, below), Cp = from_lane_rot(C, above);
+            A = -(Am * A) * rb;
+            C = -(Cp * C) * rb;
+        }
+    }
+    const double X = D;                      // this lane's last unknown
+    if constexpr (R == 1) {
+        rhs[0] = X;
+    } else {
+        const double XL = from_lane_below(X);
+#pragma unroll
+        for (int j = 0; j < R - 1; ++j) {
+            double v = __builtin_fma(-lo[j], XL, rhs[j]);
+            v = __builtin_fma(-gs[j], X, v);
+            rhs[j] = v * di[j];
+        }
+        rhs[R - 1] = X;
+    }
+}
+
+}  // namespace bg

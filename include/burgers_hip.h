@@ -1,0 +1,105 @@
+/* burgers_hip.h -- C ABI of libburgers_hip.so (MI355X / gfx950).
+ *
+ * The reference (SADPR/1D-Burgers-Equation-ROMs) is pure Python on this path and
+ * has no FFI of its own; each entry point below names the reference routine whose
+ * inner loop it replaces (file:line relative to the reference checkout).  The
+ * reference-side binding (a ctypes stub inside FEM/fem_burgers.py) is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch.Tensor.data_ptr()) unless
+ *     it is marked "host";
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL =
+ *     the null stream), allocate nothing, keep no global state and are thread-safe;
+ *   - return value: BG_OK (0) or a negative BG_ERR_* code; nothing throws;
+ *   - arrays are dense, row-major, float64 unless stated; "history" arrays are
+ *     time-major per sample, hist[b][t][i] (the reference's (N, nT+1) C-order layout
+ *     is produced by bg_transpose_batched);
+ *   - one wavefront owns one (mu1, mu2) sample for the whole time loop.
+ */
+#ifndef BURGERS_HIP_H
+#define BURGERS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BG_ABI_VERSION 1
+
+enum {
+    BG_OK = 0,
+    BG_ERR_BAD_ARG = -1,        /* null pointer, negative size, ...                       */
+    BG_ERR_UNSUPPORTED_N = -2,  /* N outside the range the wave-per-sample kernels cover  */
+    BG_ERR_NONUNIFORM = -3,     /* mesh is not uniform (fast path only handles linspace)  */
+    BG_ERR_LAUNCH = -4,         /* hipLaunchKernel failed; see bg_last_hip_error()        */
+    BG_ERR_UNSUPPORTED_R = -5,  /* reduced dimension outside the supported range          */
+    BG_ERR_PROJECTION = -6,     /* unknown projection enum                                */
+    BG_ERR_WORKSPACE = -7       /* caller-provided workspace too small                    */
+};
+
+enum { BG_PROJ_GALERKIN = 0, BG_PROJ_LSPG = 1 };
+
+/* per-sample status bits written to `flags` */
+enum { BG_FLAG_HIT_CAP = 1, BG_FLAG_NONFINITE = 2 };
+
+int bg_abi_version(void);
+const char *bg_strerror(int code);
+/* hipError_t of the most recent failed launch on the calling thread (0 if none). */
+int bg_last_hip_error(void);
+
+/* Largest / smallest N the single-wave FOM kernel handles (rows per lane <= 16). */
+int bg_fom_max_n(void);
+
+/* ---------------------------------------------------------------------------------
+ * bg_fom_run -- batched replacement of FEMBurgers.fom_burgers
+ *   reference: FEM/fem_burgers.py:646-707 (time loop + Picard loop), with
+ *   compute_convection_matrix :389-425, compute_forcing_vector :427-461,
+ *   compute_supg_term :500-581 and scipy spsolve :692 fused into one kernel.
+ *
+ *   x      [N]               mesh nodes; must be uniform (linspace) -> else BG_ERR_NONUNIFORM
+ *                            is reported by bg_mesh_is_uniform on the host side
+ *   u0     [B][N]            initial state per sample
+ *   mu1,mu2[B]               Dirichlet value u(0,t) and source exponent per sample
+ *   hist   [B][nsteps+1][N]  hist[b][0] = u0[b]; hist[b][t+1] = state after step t
+ *   iters  [B][nsteps]       Picard iterations taken per step (the reference's k)
+ *   flags  [B]               BG_FLAG_* bits
+ *   tol, max_it              the reference hard-codes 1e-6 and 20 (:663)
+ *   supg                     1 = include the SUPG vector (fom_burgers), 0 = omit
+ * --------------------------------------------------------------------------------- */
+int bg_fom_run(int N, int B, int nsteps, const double *x, const double *u0, const double *mu1,
+               const double *mu2, double dt, double E, double tol, int max_it, int supg,
+               double *hist, int32_t *iters, int32_t *flags, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * bg_fom_assemble -- one Picard assembly, for inspection and tests
+ *   reference: FEM/fem_burgers.py:666-689 (C, S, F, A with Dirichlet row, b, R).
+ *   uk, un [B][N]; outputs lo/di/up/rhs [B][N]: the three diagonals of A(u_k)
+ *   (lo[.][0] = up[.][N-1] = 0) and rhs = b - A u_k = -R.
+ * --------------------------------------------------------------------------------- */
+int bg_fom_assemble(int N, int B, const double *x, const double *uk, const double *un,
+                    const double *mu1, const double *mu2, double dt, double E, int supg,
+                    double *lo, double *di, double *up, double *rhs, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * bg_tridiag_solve -- batched pivot-free tridiagonal solve, one wavefront per system
+ *   reference: scipy.sparse.linalg.spsolve call at FEM/fem_burgers.py:692.
+ *   lo/di/up/rhs [B][N] as produced by bg_fom_assemble; sol [B][N].
+ * --------------------------------------------------------------------------------- */
+int bg_tridiag_solve(int N, int B, const double *lo, const double *di, const double *up,
+                     const double *rhs, double *sol, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * bg_transpose_batched -- out[b][c][r] = in[b][r][c]
+ *   turns the time-major history [B][nT+1][N] into the reference's (N, nT+1) C-order
+ *   snapshot layout per sample (FEM/fem_burgers.py:650, np.save at
+ *   FEM/paper_training_stage.py:52-53).
+ * --------------------------------------------------------------------------------- */
+int bg_transpose_batched(int B, int rows, int cols, const double *in, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BURGERS_HIP_H */

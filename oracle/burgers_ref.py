@@ -1,0 +1,489 @@
+"""CPU oracle for the 1-D Burgers FOM/ROM Picard ("Newton") hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the shipped
+product: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` may import it, and only as the checker.  The product path
+(``1d-burgers-equation-roms_amd/``) never imports this module and raises when
+its HIP library is missing.
+
+What it is: a NumPy/SciPy restatement of the algorithm in the reference's
+``FEM/fem_burgers.py`` (read as text; no source copied).  Element loops of the
+reference are restated as whole-array expressions over the ``N-1`` two-node
+elements while keeping the reference's order of floating-point operations
+where that is cheap (Gauss-point accumulation order, element-then-element
+assembly order, left-to-right ``M + At*C + At*E*K``).
+
+Parity: PINNED.  ``tests/test_oracle_golden.py`` checks this module against
+(i) slices of the ``.npy`` outputs the reference repository itself commits
+(FOM snapshots, POD modes, POD-PROM / quadratic-PROM solutions) and (ii)
+vectors produced by importing the reference in the build container
+(``tests/golden/make_golden.py``, committed next to its outputs).
+
+Reference citations are ``FEM/fem_burgers.py:<line>`` unless another file is
+named.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg as sla
+
+__all__ = [
+    "gauss_tables", "mass_tridiag", "diffusion_tridiag", "convection_tridiag",
+    "forcing_vector", "supg_term", "tridiag_matvec", "tridiag_solve",
+    "system_tridiag", "fom_burgers", "pod_prom_burgers", "get_sym", "get_dQ_dq",
+    "pod_quadratic_manifold", "mlp_forward", "mlp_jacobian", "pod_ann_prom",
+    "pod_basis", "n_modes_for_tolerance", "compute_H", "build_Q",
+]
+
+
+# --------------------------------------------------------------------------
+# Gauss tables                                   (fem_burgers.py:315-322)
+# --------------------------------------------------------------------------
+def gauss_tables():
+    """2-point Gauss tables: ``zgp=±1/√3``, ``wgp=[1,1]``, ``N[gp,node]``, ``Nxi``."""
+    zgp = np.array([-np.sqrt(3) / 3, np.sqrt(3) / 3])
+    wgp = np.array([1.0, 1.0])
+    N = np.array([(1 - zgp) / 2, (1 + zgp) / 2]).T      # N[gp, local node]
+    Nxi = np.array([[-0.5, 0.5], [-0.5, 0.5]])
+    return zgp, wgp, N, Nxi
+
+
+def _elem_geometry(X):
+    """Per-element Jacobian ``J = Nxi @ x_e`` and ``dV = w*|J|`` (:339-343)."""
+    X = np.asarray(X, dtype=np.float64)
+    xl, xr = X[:-1], X[1:]
+    J = -0.5 * xl + 0.5 * xr                 # dN_dxi_gp @ x_element, same for both gp
+    dV = 1.0 * np.abs(J)
+    return xl, xr, J, dV
+
+
+def _assemble_tridiag(Ell, Elr, Erl, Err):
+    """Scatter 2x2 element matrices into (lower, diag, upper) in element order."""
+    ne = Ell.shape[-1]
+    n = ne + 1
+    shp = Ell.shape[:-1]
+    lo = np.zeros(shp + (n,))
+    di = np.zeros(shp + (n,))
+    up = np.zeros(shp + (n,))
+    # node i receives [r,r] of element i-1 first, then [l,l] of element i
+    di[..., 1:] += Err
+    di[..., :-1] += Ell
+    up[..., :-1] = Elr          # A[i, i+1]
+    lo[..., 1:] = Erl           # A[i, i-1]
+    return lo, di, up
+
+
+def mass_tridiag(X):
+    """Consistent P1 mass matrix as three diagonals (:324-353)."""
+    _, _, N, _ = gauss_tables()
+    _, _, _, dV = _elem_geometry(X)
+    E = [[None, None], [None, None]]
+    for i in range(2):
+        for j in range(2):
+            acc = np.zeros_like(dV)
+            for gp in range(2):
+                acc = acc + (N[gp, i] * N[gp, j]) * dV
+            E[i][j] = acc
+    return _assemble_tridiag(E[0][0], E[0][1], E[1][0], E[1][1])
+
+
+def diffusion_tridiag(X):
+    """P1 stiffness matrix as three diagonals (:355-387)."""
+    _, _, _, Nxi = gauss_tables()
+    _, _, J, dV = _elem_geometry(X)
+    E = [[None, None], [None, None]]
+    for i in range(2):
+        for j in range(2):
+            acc = np.zeros_like(dV)
+            for gp in range(2):
+                dNi = Nxi[gp, i] / J
+                dNj = Nxi[gp, j] / J
+                acc = acc + (dNi * dNj) * dV
+            E[i][j] = acc
+    return _assemble_tridiag(E[0][0], E[0][1], E[1][0], E[1][1])
+
+
+def convection_tridiag(X, U):
+    """Convection matrix ``C(U)`` as three diagonals (:389-425).
+
+    ``U`` may be ``(N,)`` or ``(B, N)``; the diagonals carry the same leading axis.
+    """
+    _, _, N, Nxi = gauss_tables()
+    _, _, J, dV = _elem_geometry(X)
+    U = np.asarray(U, dtype=np.float64)
+    ul, ur = U[..., :-1], U[..., 1:]
+    E = [[None, None], [None, None]]
+    for i in range(2):
+        for j in range(2):
+            acc = np.zeros_like(ul)
+            for gp in range(2):
+                u_gp = N[gp, 0] * ul + N[gp, 1] * ur
+                dNj = Nxi[gp, j] / J
+                acc = acc + (N[gp, i] * (u_gp * dNj)) * dV
+            E[i][j] = acc
+    return _assemble_tridiag(E[0][0], E[0][1], E[1][0], E[1][1])
+
+
+def forcing_vector(X, mu2):
+    """Load vector of ``0.02*exp(mu2*x)`` by 2-pt Gauss (:427-461).
+
+    ``mu2`` scalar -> ``(N,)``; ``mu2`` of shape ``(B,)`` -> ``(B, N)``.
+    """
+    _, _, N, _ = gauss_tables()
+    xl, xr, _, dV = _elem_geometry(X)
+    mu2 = np.asarray(mu2, dtype=np.float64)[..., None]
+    Fl = np.zeros(mu2.shape[:-1] + xl.shape)
+    Fr = np.zeros_like(Fl)
+    for gp in range(2):
+        x_gp = N[gp, 0] * xl + N[gp, 1] * xr
+        f_gp = 0.02 * np.exp(mu2 * x_gp)
+        Fl = Fl + f_gp * N[gp, 0] * dV
+        Fr = Fr + f_gp * N[gp, 1] * dV
+    F = np.zeros(Fl.shape[:-1] + (len(xl) + 1,))
+    F[..., 1:] += Fr
+    F[..., :-1] += Fl
+    return F
+
+
+def supg_term(X, U, mu2):
+    """SUPG stabilisation vector (:500-581): ``tau_e * R(u) * dN/dx`` integrated."""
+    _, _, N, Nxi = gauss_tables()
+    xl, xr, J, dV = _elem_geometry(X)
+    U = np.asarray(U, dtype=np.float64)
+    mu2 = np.asarray(mu2, dtype=np.float64)
+    if U.ndim > 1:
+        mu2 = mu2[..., None]
+    ul, ur = U[..., :-1], U[..., 1:]
+    h_e = xr - xl
+    u_e = (ul + ur) / 2.0                                  # np.mean of two
+    vel = np.where(np.abs(u_e) > 1.0e-10, np.abs(u_e), 1.0e-10)
+    tau = 0.5 * h_e / (2.0 * vel)
+    du_dx = (ur - ul) / h_e
+    Sl = np.zeros_like(ul)
+    Sr = np.zeros_like(ul)
+    for gp in range(2):
+        x_gp = N[gp, 0] * xl + N[gp, 1] * xr
+        u_gp = N[gp, 0] * ul + N[gp, 1] * ur
+        f_gp = 0.02 * np.exp(mu2 * x_gp)
+        R_gp = (u_gp * du_dx) - f_gp
+        Sl = Sl + tau * R_gp * (Nxi[gp, 0] / J) * dV
+        Sr = Sr + tau * R_gp * (Nxi[gp, 1] / J) * dV
+    S = np.zeros(Sl.shape[:-1] + (len(xl) + 1,))
+    S[..., 1:] += Sr
+    S[..., :-1] += Sl
+    return S
+
+
+# --------------------------------------------------------------------------
+# Tridiagonal helpers (stand in for scipy.sparse csc arithmetic / SuperLU)
+# --------------------------------------------------------------------------
+def tridiag_matvec(lo, di, up, x):
+    """``A @ x`` accumulated in column order like a CSC mat-vec (:683,689)."""
+    y = np.zeros(np.broadcast(di, x).shape)
+    y[..., 1:] += lo[..., 1:] * x[..., :-1]
+    y += di * x
+    y[..., :-1] += up[..., :-1] * x[..., 1:]
+    return y
+
+
+def tridiag_solve(lo, di, up, rhs):
+    """Pivoted banded solve (LAPACK ``gbsv``) standing in for ``spsolve`` (:692)."""
+    n = di.shape[-1]
+    ab = np.zeros((3, n))
+    ab[0, 1:] = up[:-1]
+    ab[1, :] = di
+    ab[2, :-1] = lo[1:]
+    return sla.solve_banded((1, 1), ab, rhs, check_finite=False)
+
+
+def tridiag_dense(lo, di, up):
+    n = di.shape[-1]
+    A = np.zeros((n, n))
+    i = np.arange(n)
+    A[i, i] = di
+    A[i[1:], i[:-1]] = lo[1:]
+    A[i[:-1], i[1:]] = up[:-1]
+    return A
+
+
+def tridiag_matmat(lo, di, up, W):
+    """``A @ W`` for a dense ``(N, r)`` block."""
+    Y = di[:, None] * W
+    Y[1:] += lo[1:, None] * W[:-1]
+    Y[:-1] += up[:-1, None] * W[1:]
+    return Y
+
+
+def system_tridiag(M3, K3, C3, At, E):
+    """``A = M + At*C + At*E*K`` then Dirichlet row 0 (:676-680)."""
+    out = []
+    for m, c, k in zip(M3, C3, K3):
+        a = (m + At * c) + (At * E) * k
+        out.append(a)
+    lo, di, up = out
+    lo = lo.copy(); di = di.copy(); up = up.copy()
+    lo[..., 0] = 0.0
+    di[..., 0] = 1.0
+    up[..., 0] = 0.0
+    return lo, di, up
+
+
+# --------------------------------------------------------------------------
+# FOM                                               (fem_burgers.py:646-707)
+# --------------------------------------------------------------------------
+def fom_burgers(X, At, nTimeSteps, u0, mu1, E, mu2, tol=1e-6, max_it=20,
+                return_iters=False):
+    """Implicit-Euler / Picard FOM; returns ``U (N, nTimeSteps+1)``."""
+    X = np.asarray(X, dtype=np.float64)
+    n = len(X)
+    U = np.zeros((n, nTimeSteps + 1))
+    U[:, 0] = u0
+    M3 = mass_tridiag(X)
+    K3 = diffusion_tridiag(X)
+    F = forcing_vector(X, mu2)          # constant; the reference recomputes it (:673)
+    iters = np.zeros(nTimeSteps, dtype=np.int32)
+    for nstep in range(nTimeSteps):
+        Un = U[:, nstep]
+        U0 = Un
+        err = 1.0
+        k = 0
+        U1 = U0
+        Mun = tridiag_matvec(*M3, Un)
+        while err > tol and k < max_it:
+            C3 = convection_tridiag(X, U0)
+            S = supg_term(X, U0, mu2)
+            lo, di, up = system_tridiag(M3, K3, C3, At, E)
+            b = Mun + At * F - At * S
+            b[0] = mu1
+            R = tridiag_matvec(lo, di, up, U0) - b
+            dU = tridiag_solve(lo, di, up, -R)
+            U1 = U0 + dU
+            err = np.linalg.norm(dU) / np.linalg.norm(U1)
+            U0 = U1
+            k += 1
+        iters[nstep] = k
+        U[:, nstep + 1] = U1
+    return (U, iters) if return_iters else U
+
+
+# --------------------------------------------------------------------------
+# POD-Galerkin / LSPG PROM                          (fem_burgers.py:709-785)
+# --------------------------------------------------------------------------
+def _reduce(lo, di, up, R, W, projection):
+    """``Ar, br`` for Galerkin ``Wᵀ A W`` or LSPG ``(AW)ᵀ(AW)`` (:754-762)."""
+    Y = tridiag_matmat(lo, di, up, W)
+    if projection == "galerkin":
+        return W.T @ Y, W.T @ R
+    return Y.T @ Y, Y.T @ R
+
+
+def pod_prom_burgers(X, At, nTimeSteps, u0, mu1, E, mu2, Phi, projection="Galerkin",
+                     tol=1e-6, max_it=20, return_iters=False):
+    if projection not in ("Galerkin", "LSPG"):       # case-sensitive (:754-764)
+        raise ValueError(f"Projection method '{projection}' is not available. "
+                         "Please use 'Galerkin' or 'LSPG'.")
+    proj = projection.lower()
+    X = np.asarray(X, dtype=np.float64)
+    n = len(X)
+    U = np.zeros((n, nTimeSteps + 1))
+    U[:, 0] = u0
+    M3 = mass_tridiag(X)
+    K3 = diffusion_tridiag(X)
+    F = forcing_vector(X, mu2)
+    iters = np.zeros(nTimeSteps, dtype=np.int32)
+    for nstep in range(nTimeSteps):
+        Un = U[:, nstep]
+        U0 = Un
+        err, k, U1 = 1.0, 0, Un
+        Mun = tridiag_matvec(*M3, Un)
+        while err > tol and k < max_it:
+            C3 = convection_tridiag(X, U0)
+            S = supg_term(X, U0, mu2)
+            lo, di, up = system_tridiag(M3, K3, C3, At, E)
+            b = Mun + At * F - At * S
+            b[0] = mu1
+            R = tridiag_matvec(lo, di, up, U0) - b
+            Ar, br = _reduce(lo, di, up, R, Phi, proj)
+            dq = np.linalg.solve(Ar, -br)
+            q = Phi.T @ U0 + dq
+            U1 = Phi @ q
+            err = np.linalg.norm(dq) / np.linalg.norm(q)
+            U0 = U1
+            k += 1
+        iters[nstep] = k
+        U[:, nstep + 1] = U1
+    return (U, iters) if return_iters else U
+
+
+# --------------------------------------------------------------------------
+# Quadratic manifold                       (fem_burgers.py:263-312, 1081-1175)
+# --------------------------------------------------------------------------
+def get_sym(q):
+    """Unique monomials ``q_i q_j, j>=i`` in row-major upper-triangle order (:263-273)."""
+    i, j = np.triu_indices(len(q))
+    return q[i] * q[j]
+
+
+def get_dQ_dq(q):
+    """``d get_sym / dq`` of shape ``(k, n)`` (:292-312)."""
+    n = len(q)
+    i, j = np.triu_indices(n)
+    k = len(i)
+    dQ = np.zeros((k, n))
+    rows = np.arange(k)
+    diag = i == j
+    dQ[rows[diag], i[diag]] = 2.0 * q[i[diag]]
+    off = ~diag
+    dQ[rows[off], i[off]] = q[j[off]]
+    dQ[rows[off], j[off]] = q[i[off]]
+    return dQ
+
+
+def pod_quadratic_manifold(X, At, nTimeSteps, u0, uxa, E, mu2, Phi, H, projection="LSPG",
+                           newton_tol=1e-6, newton_itmax=25, return_iters=False):
+    proj = projection.lower()
+    if proj not in ("galerkin", "lspg"):
+        raise ValueError("projection must be 'Galerkin' or 'LSPG'")
+    X = np.asarray(X, dtype=np.float64)
+    n = len(X)
+    U = np.zeros((n, nTimeSteps + 1))
+    U[:, 0] = np.asarray(u0).copy()
+    M3 = mass_tridiag(X)
+    K3 = diffusion_tridiag(X)
+    F = forcing_vector(X, mu2)
+    iters = np.zeros(nTimeSteps, dtype=np.int32)
+    for m in range(nTimeSteps):
+        q = Phi.T @ U[:, m]
+        u = Phi @ q + H @ get_sym(q)
+        Mun = tridiag_matvec(*M3, U[:, m])
+        it_done = 0
+        for it in range(newton_itmax):
+            C3 = convection_tridiag(X, u)
+            lo, di, up = system_tridiag(M3, K3, C3, At, E)
+            b = Mun + At * F                          # no SUPG in this variant (:1142)
+            b[0] = uxa
+            R = tridiag_matvec(lo, di, up, u) - b
+            T = Phi + H @ get_dQ_dq(q)
+            Ar, br = _reduce(lo, di, up, R, T, proj)
+            dq = np.linalg.solve(Ar, -br)
+            q = q + dq
+            u = Phi @ q + H @ get_sym(q)
+            rel = np.linalg.norm(dq) / max(1e-14, np.linalg.norm(q))
+            it_done = it + 1
+            if rel < newton_tol:
+                break
+        iters[m] = it_done
+        U[:, m + 1] = u
+    return (U, iters) if return_iters else U
+
+
+# --------------------------------------------------------------------------
+# POD-ANN                                     (fem_burgers.py:1177-1275)
+# --------------------------------------------------------------------------
+def _elu32(x):
+    x = x.astype(np.float32, copy=False)
+    return np.where(x > 0, x, np.expm1(np.minimum(x, np.float32(0))).astype(np.float32))
+
+
+def mlp_forward(weights, biases, q_p):
+    """fp32 MLP with ELU between layers (``POD-ANN/pod_ann.py:38-56``)."""
+    x = np.asarray(q_p, dtype=np.float32)
+    L = len(weights)
+    for i, (W, b) in enumerate(zip(weights, biases)):
+        x = (x @ W.T.astype(np.float32) + b.astype(np.float32)).astype(np.float32)
+        if i < L - 1:
+            x = _elu32(x)
+    return x
+
+
+def mlp_jacobian(weights, biases, q_p):
+    """fp32 input-Jacobian ``(nbar, n)``; analytic stand-in for
+    ``torch.autograd.functional.jacobian`` (:1254-1275)."""
+    x = np.asarray(q_p, dtype=np.float32)
+    J = np.eye(len(x), dtype=np.float32)
+    L = len(weights)
+    for i, (W, b) in enumerate(zip(weights, biases)):
+        W = W.astype(np.float32)
+        z = (W @ x + b.astype(np.float32)).astype(np.float32)
+        J = (W @ J).astype(np.float32)
+        if i < L - 1:
+            d = np.where(z > 0, np.float32(1), np.exp(np.minimum(z, np.float32(0)))).astype(np.float32)
+            J = (d[:, None] * J).astype(np.float32)
+            x = _elu32(z)
+        else:
+            x = z
+    return J
+
+
+def pod_ann_prom(X, At, nTimeSteps, u0, mu1, E, mu2, U_p, U_s, weights, biases,
+                 projection="LSPG", tol=1e-6, max_it=50, return_iters=False):
+    proj = projection.lower()
+    if proj not in ("galerkin", "lspg"):
+        raise ValueError("projection must be 'Galerkin' or 'LSPG'")
+    X = np.asarray(X, dtype=np.float64)
+    n = len(X)
+    U = np.zeros((n, nTimeSteps + 1))
+    U[:, 0] = u0
+    M3 = mass_tridiag(X)
+    K3 = diffusion_tridiag(X)
+    F = forcing_vector(X, mu2)
+    iters = np.zeros(nTimeSteps, dtype=np.int32)
+    for nt in range(nTimeSteps):
+        U0 = U[:, nt].copy()
+        q_p = U_p.T @ U0
+        Mun = tridiag_matvec(*M3, U[:, nt])
+        err, it, U1 = 1.0, 0, U0
+        while err > tol and it < max_it:
+            C3 = convection_tridiag(X, U0)
+            S = supg_term(X, U0, mu2)
+            lo, di, up = system_tridiag(M3, K3, C3, At, E)
+            b = Mun + At * F - At * S
+            b[0] = mu1
+            R = tridiag_matvec(lo, di, up, U0) - b
+            dN = mlp_jacobian(weights, biases, q_p.astype(np.float32)).astype(np.float64)
+            dD = U_p + U_s @ dN
+            Ar, br = _reduce(lo, di, up, R, dD, proj)
+            dq = np.linalg.solve(Ar, -br)
+            q_p = q_p + dq
+            q_s = mlp_forward(weights, biases, q_p.astype(np.float32)).astype(np.float64)
+            U1 = U_p @ q_p + U_s @ q_s
+            err = np.linalg.norm(dq) / (np.linalg.norm(q_p) + 1e-14)
+            U0 = U1
+            it += 1
+        iters[nt] = it
+        U[:, nt + 1] = U1
+    return (U, iters) if return_iters else U
+
+
+# --------------------------------------------------------------------------
+# Offline bases                     (POD/pod.py:8-14,68-90; quad_utils.py)
+# --------------------------------------------------------------------------
+def n_modes_for_tolerance(s, epsilon_squared):
+    """``K = argmax(1 - cumsum(σ²)/Σσ² <= ε²) + 1`` (``POD/pod.py:8-14``)."""
+    s_sorted = np.sort(s)[::-1]
+    c = np.cumsum(s_sorted ** 2)
+    loss = 1.0 - c / c[-1]
+    return int(np.argmax(loss <= epsilon_squared) + 1)
+
+
+def pod_basis(snapshots, epsilon_squared):
+    """Thin SVD + energy truncation (``POD/pod.py:80-90``): ``(U[:, :K], s[:K])``."""
+    Um, s, _ = np.linalg.svd(snapshots, full_matrices=False)
+    K = n_modes_for_tolerance(s, epsilon_squared)
+    return Um[:, :K], s[:K]
+
+
+def build_Q(q):
+    """``Q (k, Ns)`` of unique monomials (``Quadratic_manifold/quad_utils.py:21-31``)."""
+    i, j = np.triu_indices(q.shape[0])
+    return q[i] * q[j]
+
+
+def compute_H(Q, Em, alpha):
+    """Ridge fit ``min ||E - H Q||² + α²||H||²`` by thin SVD of Q
+    (``Quadratic_manifold/quad_utils.py:63-81``)."""
+    Uq, s, VqT = np.linalg.svd(Q, full_matrices=False)
+    s2 = s ** 2
+    f = s2 / (s2 + alpha ** 2)
+    Gamma = (VqT @ Em.T) / s[:, None]
+    return ((Uq * f) @ Gamma).T

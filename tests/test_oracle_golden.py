@@ -1,0 +1,125 @@
+"""Pins the oracle (oracle/burgers_ref.py and the C restatement) to the reference:
+golden vectors produced by importing the reference (tests/golden/make_golden.py) and
+column slices of the .npy results the reference repository commits."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+from oracle import burgers_ref as br
+from oracle import burgers_ref_c as bc
+
+
+def test_assemblers_general_mesh():
+    g = load_golden("fom_general.npz")
+    X, u, mu2 = g["X"], g["u"], float(g["mu2"])
+    assert np.abs(br.tridiag_dense(*br.mass_tridiag(X)) - g["M"]).max() < 1e-15
+    assert np.abs(br.tridiag_dense(*br.diffusion_tridiag(X)) - g["K"]).max() < 1e-14
+    assert np.abs(br.tridiag_dense(*br.convection_tridiag(X, u)) - g["C"]).max() < 1e-14
+    assert np.abs(br.forcing_vector(X, mu2) - g["F"]).max() < 1e-15
+    assert np.abs(br.supg_term(X, u, mu2) - g["S"]).max() < 1e-14
+    # eps_vel branch of tau_e (|u_e| <= 1e-10): huge tau, compare relatively
+    S_small = br.supg_term(X, g["u_small"], mu2)
+    assert np.abs(S_small - g["S_small"]).max() <= 1e-13 * np.abs(g["S_small"]).max()
+
+
+def test_fom_general_mesh_live_reference():
+    g = load_golden("fom_general.npz")
+    U, it = br.fom_burgers(g["X"], float(g["At"]), int(g["nT"]), g["u0"], float(g["mu1"]), float(g["E"]),
+                           float(g["mu2"]), return_iters=True)
+    assert rel_l2(U, g["U"]) < 1e-13
+    assert np.array_equal(it, g["iters"])
+    h, itc = bc.fom_run(g["X"], g["u0"], float(g["mu1"]), float(g["mu2"]), float(g["At"]), int(g["nT"]),
+                        E=float(g["E"]))
+    assert rel_l2(h[0].T, g["U"]) < 1e-13
+    assert np.array_equal(itc[0], g["iters"])
+
+
+def test_fom_config1_n256_live_reference():
+    g = load_golden("fom_n256.npz")
+    U, it = br.fom_burgers(g["X"], float(g["At"]), int(g["nT"]), np.ones(256), float(g["mu1"]), 0.0,
+                           float(g["mu2"]), return_iters=True)
+    assert rel_l2(U, g["U"]) < 1e-13
+    assert np.array_equal(it, g["iters"])
+    assert int(it.sum()) == 840          # 840 Newton-steps
+    h, itc = bc.fom_run(g["X"], np.ones(256), float(g["mu1"]), float(g["mu2"]), float(g["At"]), int(g["nT"]))
+    assert rel_l2(h[0].T, g["U"]) < 1e-13 and np.array_equal(itc[0], g["iters"])
+
+
+def test_fom_config2_n1024_live_reference():
+    g = load_golden("fom_n1024.npz")
+    mus = g["mus"]
+    h, itc = bc.fom_run(g["X"], np.ones(1024), mus[:, 0], mus[:, 1], float(g["At"]), int(g["nT"]))
+    for b in range(len(mus)):
+        assert rel_l2(h[b].T, g["U"][b]) < 1e-13
+        assert np.array_equal(itc[b], g["iters"][b])
+    U, it = br.fom_burgers(g["X"], float(g["At"]), int(g["nT"]), np.ones(1024), mus[0, 0], 0.0, mus[0, 1],
+                           return_iters=True)
+    assert rel_l2(U, g["U"][0]) < 1e-13 and np.array_equal(it, g["iters"][0])
+
+
+@pytest.mark.parametrize("key,mu1,mu2", [("4.250_0.0150", 4.25, 0.015), ("5.500_0.0300", 5.5, 0.03),
+                                         ("4.750_0.0200", 4.75, 0.02), ("6.200_0.0400", 6.2, 0.04)])
+def test_fom_committed_snapshots_n512(key, mu1, mu2):
+    """The reference's committed (512, 501) snapshots, first 21 columns and 9 column slices."""
+    g = load_golden("committed_fom_n512.npz")
+    X = np.linspace(0, 100, 512)
+    h, _ = bc.fom_run(X, np.ones(512), mu1, mu2, 0.05, 500)
+    U = h[0].T
+    assert rel_l2(U[:, :21], g["first21_" + key]) < 1e-12
+    assert rel_l2(U[:, g["cols"]], g["U_" + key]) < 1e-10
+    Un = br.fom_burgers(X, 0.05, 20, np.ones(512), mu1, 0.0, mu2)
+    assert rel_l2(Un, g["first21_" + key]) < 1e-13
+
+
+def test_pod_truncation_rule_and_committed_prom():
+    g = load_golden("committed_pod_r40.npz")
+    Ks = [br.n_modes_for_tolerance(g["s_all"], e) for e in g["eps2"]]
+    assert Ks == list(g["K_expected"])           # 9, 40, 96, 160, 227
+    X = np.linspace(0, 100, 512)
+    for tag, proj in (("galerkin", "Galerkin"), ("lspg", "LSPG")):
+        U = br.pod_prom_burgers(X, 0.05, 12, np.ones(512), 4.75, 0.0, 0.02, g["Phi"], projection=proj)
+        assert rel_l2(U, g["first13_" + tag]) < 1e-11
+
+
+def test_pod_live_reference():
+    g = load_golden("pod_live_r40.npz")
+    Phi = load_golden("committed_pod_r40.npz")["Phi"]
+    X = np.linspace(0, 100, 512)
+    for proj in ("Galerkin", "LSPG"):
+        U, it = br.pod_prom_burgers(X, float(g["At"]), int(g["nT"]), np.ones(512), float(g["mu1"]), 0.0,
+                                    float(g["mu2"]), Phi, projection=proj, return_iters=True)
+        assert rel_l2(U, g["U_" + proj]) < 1e-11
+        assert np.array_equal(it, g["iters_" + proj])
+    with pytest.raises(ValueError):
+        br.pod_prom_burgers(X, 0.05, 1, np.ones(512), 5.0, 0.0, 0.02, Phi, projection="lspg")
+
+
+def test_quadratic_helpers_and_committed():
+    g = load_golden("quadratic_live_n21.npz")
+    assert np.array_equal(br.get_sym(g["q"]), g["sym"])
+    assert np.array_equal(br.get_dQ_dq(g["q"]), g["dQ"])
+    c = load_golden("committed_quadratic_n21.npz")
+    X = np.linspace(0, 100, 512)
+    for proj in ("Galerkin", "LSPG"):
+        U, it = br.pod_quadratic_manifold(X, float(g["At"]), int(g["nT"]), np.ones(512), float(g["mu1"]), 0.0,
+                                          float(g["mu2"]), c["Phi"], c["H"], projection=proj, return_iters=True)
+        assert rel_l2(U, g["U_" + proj]) < 1e-10
+        assert np.array_equal(it, g["iters_" + proj])
+    U = br.pod_quadratic_manifold(X, 0.05, 6, np.ones(512), float(c["mu1"]), 0.0, float(c["mu2"]), c["Phi"], c["H"])
+    assert rel_l2(U, c["first7"]) < 1e-10
+
+
+def test_ann_forward_jacobian_and_prom():
+    g = load_golden("ann_n5.npz")
+    Ws = [g[f"W{i}"] for i in range(6)]
+    bs = [g[f"b{i}"] for i in range(6)]
+    for i in range(len(g["qp"])):
+        f = br.mlp_forward(Ws, bs, g["qp"][i])
+        J = br.mlp_jacobian(Ws, bs, g["qp"][i])
+        assert np.abs(f - g["fwd"][i]).max() <= 2e-5 * max(1.0, np.abs(g["fwd"][i]).max())
+        assert np.abs(J - g["jac"][i]).max() <= 2e-4 * max(1.0, np.abs(g["jac"][i]).max())
+    X = np.linspace(0, 100, 512)
+    U, it = br.pod_ann_prom(X, float(g["At"]), int(g["nT"]), np.ones(512), float(g["mu1"]), 0.0, float(g["mu2"]),
+                            g["U_p"], g["U_s"], Ws, bs, return_iters=True)
+    # the reference evaluates the MLP and its Jacobian in fp32: parity is fp32-limited
+    assert rel_l2(U, g["U"]) < 5e-6
