@@ -1,0 +1,291 @@
+"""Batched projection-ROM time-steppers (host orchestration over the C ABI).
+
+Each Picard / Gauss-Newton iteration of the whole batch is
+    bg_rom_reduce (HIP: assembly + fp64-MFMA projection)  ->  bg_lu_solve (HIP: pivoted r x r solve)
+    ->  family-specific update (plain dense contractions over the batch: torch / rocBLAS).
+Samples carry an ``active`` flag; converged samples are skipped by the kernels and frozen
+by the masked update, so every sample follows exactly the reference's own loop:
+  pod_prom_burgers        FEM/fem_burgers.py:709-785
+  pod_quadratic_manifold  FEM/fem_burgers.py:1081-1175
+  pod_ann_prom            FEM/fem_burgers.py:1177-1251
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .fom import FomResult, _as_dev, check_mesh
+
+PROJ = {"galerkin": _lib.BG_PROJ_GALERKIN, "lspg": _lib.BG_PROJ_LSPG}
+
+
+class SingularReducedSystem(np.linalg.LinAlgError):
+    """np.linalg.solve raises LinAlgError('Singular matrix') at the same place (:767)."""
+
+
+@dataclass
+class _Common:
+    L: object
+    device: torch.device
+    X: torch.Tensor
+    N: int
+    B: int
+    mu1: torch.Tensor
+    mu2: torch.Tensor
+    u0: torch.Tensor
+    fdt: torch.Tensor
+    hfs: torch.Tensor
+    dt: float
+    E: float
+
+    def stream(self):
+        return _lib.stream_ptr(self.device)
+
+
+def _setup(X, u0, mu1, mu2, dt, E, device):
+    L = _lib.load()
+    device = _lib.require_device(device)
+    check_mesh(X)
+    Xd = _as_dev(X, device)
+    N = Xd.numel()
+    if N > L.bg_rom_max_n():
+        raise NotImplementedError(f"ROM kernels cover N <= {L.bg_rom_max_n()} (got {N})")
+    mu1d = _as_dev(mu1, device).reshape(-1)
+    mu2d = _as_dev(mu2, device).reshape(-1)
+    B = max(mu1d.numel(), mu2d.numel())
+    mu1d, mu2d = mu1d.expand(B).contiguous(), mu2d.expand(B).contiguous()
+    u0d = _as_dev(u0, device)
+    if u0d.dim() == 1:
+        u0d = u0d.unsqueeze(0)
+    u0d = u0d.expand(B, N).contiguous()
+    fdt = torch.empty((B, N), dtype=torch.float64, device=device)
+    hfs = torch.empty((B, N), dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        for b0 in range(0, B, 32768):
+            b1 = min(B, b0 + 32768)
+            _lib.check(L.bg_forcing_setup(N, b1 - b0, _lib.ptr(Xd), _lib.ptr(mu2d[b0:b1]), float(dt),
+                                          _lib.ptr(fdt[b0:b1]), _lib.ptr(hfs[b0:b1]), _lib.stream_ptr(device)),
+                       "bg_forcing_setup")
+    return _Common(L, device, Xd, N, B, mu1d, mu2d, u0d, fdt, hfs, float(dt), float(E))
+
+
+def _mass_rhs(c, Un, out):
+    with torch.cuda.device(c.device):
+        for b0 in range(0, c.B, 32768):
+            b1 = min(c.B, b0 + 32768)
+            _lib.check(c.L.bg_mass_rhs(c.N, b1 - b0, _lib.ptr(c.X), _lib.ptr(Un[b0:b1]), _lib.ptr(c.fdt[b0:b1]),
+                                       _lib.ptr(out[b0:b1]), c.stream()), "bg_mass_rhs")
+    return out
+
+
+def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None):
+    """Ar, br (and optionally W^T u) of every active sample.  W: (N, r) shared or (B, N, r)."""
+    r = W.shape[-1]
+    stride = 0 if W.dim() == 2 else c.N * r
+    with torch.cuda.device(c.device):
+        rc = c.L.bg_rom_reduce(c.N, c.B, r, proj, _lib.ptr(c.X), _lib.ptr(W), stride, _lib.ptr(U), _lib.ptr(G),
+                               _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, 1 if supg else 0,
+                               _lib.ptr(active) if active is not None else None, _lib.ptr(Ar), _lib.ptr(br),
+                               _lib.ptr(wtu) if wtu is not None else None, c.stream())
+    if rc == _lib.BG_ERR_UNSUPPORTED_R:
+        raise NotImplementedError(f"ROM kernels cover r <= {c.L.bg_rom_max_r()} (got {r})")
+    _lib.check(rc, "bg_rom_reduce")
+
+
+def lu_solve(A, b, sign=1.0, active=None, x=None, info=None):
+    """x = solve(A, sign*b) for a batch of (n, n) systems on the device."""
+    L = _lib.load()
+    device = _lib.require_device(A.device)
+    B, n, _ = A.shape
+    x = torch.empty((B, n), dtype=torch.float64, device=device) if x is None else x
+    info = torch.zeros((B,), dtype=torch.int32, device=device) if info is None else info
+    with torch.cuda.device(device):
+        rc = L.bg_lu_solve(n, B, _lib.ptr(A), _lib.ptr(b), float(sign),
+                           _lib.ptr(active) if active is not None else None, _lib.ptr(x), _lib.ptr(info),
+                           _lib.stream_ptr(device))
+    if rc == _lib.BG_ERR_UNSUPPORTED_R:
+        raise NotImplementedError("bg_lu_solve covers n <= 64")
+    _lib.check(rc, "bg_lu_solve")
+    return x, info
+
+
+def _poll(active, info):
+    """One host readback per batched iteration: (#active samples, any singular pivot)."""
+    s = torch.stack([active.sum(), (info != 0).sum().to(active.dtype)]).cpu()
+    if int(s[1]) != 0:
+        raise SingularReducedSystem("Singular matrix")
+    return int(s[0])
+
+
+def _alloc_hist(c, nsteps):
+    hist = torch.empty((c.B, nsteps + 1, c.N), dtype=torch.float64, device=c.device)
+    hist[:, 0] = c.u0
+    iters = torch.zeros((c.B, nsteps), dtype=torch.int32, device=c.device)
+    flags = torch.zeros((c.B,), dtype=torch.int32, device=c.device)
+    return hist, iters, flags
+
+
+def _workspace(c, r):
+    f64 = dict(dtype=torch.float64, device=c.device)
+    return (torch.zeros((c.B, r, r), **f64), torch.zeros((c.B, r), **f64), torch.zeros((c.B, r), **f64),
+            torch.zeros((c.B, r), **f64), torch.zeros((c.B,), dtype=torch.int32, device=c.device),
+            torch.empty((c.B, c.N), **f64))
+
+
+# --------------------------------------------------------------------------- POD
+def pod_prom_run(X, u0, mu1, mu2, dt, nsteps, Phi, projection="Galerkin", E=0.0, tol=1e-6, max_it=20,
+                 device=None):
+    """Batched ``pod_prom_burgers``; ``projection`` is case-sensitive like the reference (:754-764)."""
+    if projection not in ("Galerkin", "LSPG"):
+        raise ValueError(f"Projection method '{projection}' is not available. Please use 'Galerkin' or 'LSPG'.")
+    proj = PROJ[projection.lower()]
+    c = _setup(X, u0, mu1, mu2, dt, E, device)
+    Phid = _as_dev(Phi, c.device)
+    if Phid.shape[0] != c.N:
+        raise ValueError("Phi must have one row per mesh node")
+    r = Phid.shape[1]
+    PhiT = Phid.t().contiguous()
+    hist, iters, flags = _alloc_hist(c, nsteps)
+    Ar, br, wtu, dq, info, G = _workspace(c, r)
+    U0 = c.u0.clone()
+    for n in range(nsteps):
+        _mass_rhs(c, U0, G)
+        active = torch.ones((c.B,), dtype=torch.int32, device=c.device)
+        k = torch.zeros_like(active)
+        while True:
+            rom_reduce(c, Phid, U0, G, proj, True, active, Ar, br, wtu)
+            lu_solve(Ar, br, -1.0, active, dq, info)
+            q = wtu + dq                                   # q = Phi^T U0 + dq      (:770)
+            U1 = q @ PhiT                                  # U1 = Phi q             (:773)
+            err = torch.linalg.vector_norm(dq, dim=1) / torch.linalg.vector_norm(q, dim=1)
+            act = active.bool()
+            U0 = torch.where(act[:, None], U1, U0)
+            k += active
+            nonfin = act & ~torch.isfinite(err)
+            flags |= nonfin.to(torch.int32) * _lib.BG_FLAG_NONFINITE
+            active = (act & (err > tol) & (k < max_it)).to(torch.int32)
+            if _poll(active, info) == 0:
+                break
+        flags |= (k >= max_it).to(torch.int32) * _lib.BG_FLAG_HIT_CAP
+        iters[:, n] = k
+        hist[:, n + 1] = U0
+    return FomResult(hist, iters, flags)
+
+
+# ------------------------------------------------------------ quadratic manifold
+def sym_index_tables(n, device):
+    """Row-major upper-triangle pair order of get_sym (:263-273) and the (n, n) lookup of
+    the pair index, with the factor (1 + delta_ab) of get_dQ_dq (:292-312)."""
+    I, J = np.triu_indices(n)
+    idx = np.zeros((n, n), dtype=np.int64)
+    idx[I, J] = np.arange(len(I))
+    idx[J, I] = np.arange(len(I))
+    fac = np.ones((n, n)) + np.eye(n)
+    return (torch.as_tensor(I, device=device), torch.as_tensor(J, device=device),
+            torch.as_tensor(idx, device=device), torch.as_tensor(fac, device=device))
+
+
+def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0, newton_tol=1e-6,
+                  newton_itmax=25, device=None):
+    """Batched ``pod_quadratic_manifold`` (no SUPG term in this variant, :1142)."""
+    p = projection.lower()
+    if p not in PROJ:
+        raise ValueError("projection must be 'Galerkin' or 'LSPG'")
+    proj = PROJ[p]
+    c = _setup(X, u0, mu1, mu2, dt, E, device)
+    Phid, Hd = _as_dev(Phi, c.device), _as_dev(np.ascontiguousarray(H) if isinstance(H, np.ndarray) else H, c.device)
+    n = Phid.shape[1]
+    kk = n * (n + 1) // 2
+    if Hd.shape != (c.N, kk) or Phid.shape[0] != c.N:
+        raise ValueError("Phi must be (N, n) and H (N, n(n+1)/2)")
+    I, J, idx, fac = sym_index_tables(n, c.device)
+    PhiT, HT = Phid.t().contiguous(), Hd.t().contiguous()
+    # H3[i, a, b] = H[i, pair(a, b)] * (1 + delta_ab):  tangent = Phi + H3 . q   (:1120-1123)
+    H3 = (Hd[:, idx] * fac).reshape(c.N * n, n).contiguous()
+
+    def decode(q):                                           # Phi q + H Q(q)        (:1116-1118)
+        return q @ PhiT + (q[:, I] * q[:, J]) @ HT
+
+    hist, iters, flags = _alloc_hist(c, nsteps)
+    Ar, br, _, dq, info, G = _workspace(c, n)
+    Un = c.u0.clone()
+    for m in range(nsteps):
+        _mass_rhs(c, Un, G)
+        q = Un @ Phid                                        # first guess            (:1129)
+        u = decode(q)
+        active = torch.ones((c.B,), dtype=torch.int32, device=c.device)
+        k = torch.zeros_like(active)
+        for it in range(newton_itmax):
+            T = (Phid.reshape(1, c.N, n) + (q @ H3.t()).reshape(c.B, c.N, n)).contiguous()
+            rom_reduce(c, T, u, G, proj, False, active, Ar, br, None)
+            lu_solve(Ar, br, -1.0, active, dq, info)
+            act = active.bool()
+            qn = q + dq
+            q = torch.where(act[:, None], qn, q)
+            u = torch.where(act[:, None], decode(q), u)
+            rel = torch.linalg.vector_norm(dq, dim=1) / torch.clamp(torch.linalg.vector_norm(q, dim=1), min=1e-14)
+            k += active
+            active = (act & ~(rel < newton_tol)).to(torch.int32)       # `if rel < tol: break` (:1169)
+            if _poll(active, info) == 0:
+                break
+        flags |= active * _lib.BG_FLAG_HIT_CAP                         # "Newton did not converge" (:1171)
+        iters[:, m] = k
+        hist[:, m + 1] = u
+        Un = u
+    return FomResult(hist, iters, flags)
+
+
+# ----------------------------------------------------------------------- POD-ANN
+def ann_jacobian(model, q32):
+    """Batched input-Jacobian (B, nbar, n) of ``model`` in fp32; forward mode, since n << nbar.
+    Stand-in for the per-sample torch.autograd.functional.jacobian of :1254-1275."""
+    from torch.func import jacfwd, vmap
+    return vmap(jacfwd(lambda z: model(z.unsqueeze(0)).squeeze(0)))(q32)
+
+
+def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG", E=0.0, tol=1e-6, max_it=50,
+                device=None, ann_dtype=torch.float32):
+    """Batched ``pod_ann_prom``.  The MLP and its Jacobian are evaluated in ``ann_dtype`` (the
+    reference uses float32, :1219,:1241) through PyTorch-ROCm; everything else is fp64."""
+    p = projection.lower()
+    if p not in PROJ:
+        raise ValueError("projection must be 'Galerkin' or 'LSPG'")
+    proj = PROJ[p]
+    c = _setup(X, u0, mu1, mu2, dt, E, device)
+    Up, Us = _as_dev(U_p, c.device), _as_dev(U_s, c.device)
+    n = Up.shape[1]
+    UpT, UsT = Up.t().contiguous(), Us.t().contiguous()
+    model = model.to(device=c.device, dtype=ann_dtype)
+    hist, iters, flags = _alloc_hist(c, nsteps)
+    Ar, br, _, dq, info, G = _workspace(c, n)
+    U0 = c.u0.clone()
+    for nt in range(nsteps):
+        _mass_rhs(c, U0, G)
+        qp = U0 @ Up                                                       # (:1197)
+        active = torch.ones((c.B,), dtype=torch.int32, device=c.device)
+        k = torch.zeros_like(active)
+        while True:
+            with torch.no_grad():
+                dN = ann_jacobian(model, qp.to(ann_dtype)).to(torch.float64)    # (B, nbar, n)
+            dD = (Up.unsqueeze(0) + torch.matmul(Us, dN)).contiguous()      # U_p + U_s dN        (:1224)
+            rom_reduce(c, dD, U0, G, proj, True, active, Ar, br, None)
+            lu_solve(Ar, br, -1.0, active, dq, info)
+            act = active.bool()
+            qp = torch.where(act[:, None], qp + dq, qp)
+            with torch.no_grad():
+                qs = model(qp.to(ann_dtype)).to(torch.float64)
+            U1 = qp @ UpT + qs @ UsT                                        # (:1242)
+            U0 = torch.where(act[:, None], U1, U0)
+            err = torch.linalg.vector_norm(dq, dim=1) / (torch.linalg.vector_norm(qp, dim=1) + 1e-14)
+            k += active
+            active = (act & (err > tol) & (k < max_it)).to(torch.int32)
+            if _poll(active, info) == 0:
+                break
+        flags |= (k >= max_it).to(torch.int32) * _lib.BG_FLAG_HIT_CAP
+        iters[:, nt] = k
+        hist[:, nt + 1] = U0
+    return FomResult(hist, iters, flags)

@@ -1,0 +1,440 @@
+// rom.hip -- batched projection-ROM kernels for gfx950 and their C-ABI entry points.
+//
+// One Picard/Gauss-Newton iteration of the reference's ROM time-steppers
+// (FEM/fem_burgers.py: pod_prom_burgers :709-785, pod_quadratic_manifold :1081-1175,
+// pod_ann_prom :1177-1251) is, per sample,
+//     assemble A(u), R(u)            -> fused into bg_rom_reduce (same arithmetic as the FOM)
+//     Ar = W^T A W | (A W)^T (A W)   -> bg_rom_reduce, fp64 MFMA 16x16x4, W = basis / tangent
+//     br = W^T R   | (A W)^T R       -> same kernel (extra B-operand column)
+//     dq = solve(Ar, -br)            -> bg_lu_solve (partial pivoting, one wavefront per system)
+// The decode / tangent steps that differ between the three ROM families are plain dense
+// contractions over the whole batch and live on the host side (burgers_hip/rom.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/burgers_hip.h"
+#include "fom_device.hpp"
+
+namespace {
+
+using namespace bg;
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+int check_launch_rom()
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? BG_OK : BG_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------
+// Per-sample constants: fdt[b][i] = dt*F_i(mu2_b), hfs[b][e] = h*(f(gp1)+f(gp2)) of element e
+// (hfs[b][N-1] = 0).  reference: compute_forcing_vector :427-461 and the f_gp of :556-558.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void forcing_setup_kernel(const double* __restrict__ x,
+                                                            const double* __restrict__ mu2, int N, int B,
+                                                            double dt, double* __restrict__ fdt,
+                                                            double* __restrict__ hfs)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N || b >= B) return;
+    const double h = (x[N - 1] - x[0]) / (double)(N - 1);
+    const double m = mu2[b];
+    double frPrev = 0.0, fl = 0.0, fs = 0.0;
+    if (i > 0) {
+        const double xl = x[i - 1], xr = x[i];
+        const double f1 = 0.02 * exp(m * (GP_A * xl + GP_B * xr));
+        const double f2 = 0.02 * exp(m * (GP_B * xl + GP_A * xr));
+        frPrev = (f1 * GP_B + f2 * GP_A) * (0.5 * h);
+    }
+    if (i < N - 1) {
+        const double xl = x[i], xr = x[i + 1];
+        const double f1 = 0.02 * exp(m * (GP_A * xl + GP_B * xr));
+        const double f2 = 0.02 * exp(m * (GP_B * xl + GP_A * xr));
+        fl = (f1 * GP_A + f2 * GP_B) * (0.5 * h);
+        fs = f1 + f2;
+    }
+    fdt[(size_t)b * N + i] = dt * (frPrev + fl);
+    hfs[(size_t)b * N + i] = h * fs;
+}
+
+// g = M u^n + dt F      reference: `M @ U[:, n] + At*F` of :683
+__global__ __launch_bounds__(256) void mass_rhs_kernel(const double* __restrict__ x,
+                                                       const double* __restrict__ un,
+                                                       const double* __restrict__ fdt, int N, int B,
+                                                       double* __restrict__ g)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N || b >= B) return;
+    const double h6 = (x[N - 1] - x[0]) / (double)(N - 1) / 6.0;
+    const double* u = un + (size_t)b * N;
+    double acc;
+    if (i == 0)
+        acc = __builtin_fma(2.0, u[0], u[1]);
+    else if (i == N - 1)
+        acc = __builtin_fma(2.0, u[i], u[i - 1]);
+    else
+        acc = __builtin_fma(4.0, u[i], u[i - 1]) + u[i + 1];
+    g[(size_t)b * N + i] = __builtin_fma(h6, acc, fdt[(size_t)b * N + i]);
+}
+
+// ------------------------------------------------------------------------------------
+// bg_rom_reduce: fused assembly + projection.
+//   workgroup = 4 wavefronts; wave w, lane (g = lane>>4, c = lane&15) owns the mesh rows
+//   i = (4w + g)*S + s, s = 0..S-1 as the K index of v_mfma_f64_16x16x4_f64 (k = g), so the
+//   rows i-1, i, i+1 needed by the tridiagonal apply Y = A W sit in the SAME lane's adjacent
+//   fragment registers.  Fragment t of step s holds W[i][16 t + c].  With a shared basis
+//   (w_stride == 0) the fragments are loaded once per workgroup and stay in registers
+//   while the workgroup walks over its samples.
+// ------------------------------------------------------------------------------------
+struct ReduceArgs {
+    const double* x;
+    const double* W;         // [N][r] (shared) or [B][N][r]
+    long long w_stride;      // 0 = shared
+    const double* U;         // [B][N]  current iterate
+    const double* G;         // [B][N]  M u^n + dt F
+    const double* hfs;       // [B][N]
+    const double* mu1;       // [B]
+    const int32_t* active;   // [B] or null
+    double* Ar;              // [B][r][r]
+    double* br;              // [B][r]
+    double* wtu;             // [B][r]  W^T u  (null = skip)
+    double dt, E;
+    int N, B, r, proj, supg;
+};
+
+template <int S, int NT>
+__global__ __launch_bounds__(256, 1) void rom_reduce_kernel(ReduceArgs a)
+{
+    constexpr int NPAD = 16 * S;
+    constexpr int RP = 16 * NT;             // padded reduced dimension
+    __shared__ double s_u[NPAD + 2];        // u with one halo entry on each side
+    __shared__ double s_coef[NPAD][4];      // lo, di, up, rhs(= -R) per row
+    __shared__ double s_red[4][RP][RP + 1]; // per-wave partial Ar | br
+    __shared__ double s_q[4][4][RP];        // per-wave, per-group partial W^T u
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int N = a.N, r = a.r;
+    const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
+    const MeshConst mc = make_mesh_const(h, a.dt, a.E, a.supg);
+    const int rowbase = (4 * w + g) * S;
+
+    double frag[NT][S + 2];                 // W[rowbase + s - 1][16 t + c], s = 0..S+1
+    bool have_frags = false;
+
+    for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
+        if (a.active && a.active[smp] == 0) continue;        // workgroup-uniform
+        // ---- basis / tangent fragments --------------------------------------------------
+        if (a.w_stride != 0 || !have_frags) {
+            const double* Wp = a.W + (size_t)smp * (size_t)a.w_stride;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = 16 * t + c;
+#pragma unroll
+                for (int s = 0; s < S + 2; ++s) {
+                    const int i = rowbase + s - 1;
+                    frag[t][s] = (i >= 0 && i < N && col < r) ? Wp[(size_t)i * r + col] : 0.0;
+                }
+            }
+            have_frags = true;
+        }
+        // ---- stage u, assemble the tridiagonal system into LDS ------------------------------
+        const double* up_ = a.U + (size_t)smp * N;
+        for (int i = tid; i < NPAD + 2; i += 256) {
+            const int gi = i - 1;
+            s_u[i] = (gi >= 0 && gi < N) ? up_[gi] : 0.0;
+        }
+        __syncthreads();
+        const double mu1 = a.mu1[smp];
+        for (int i = tid; i < NPAD; i += 256) {
+            double lo = 0.0, di = 1.0, up = 0.0, rhs = 0.0;
+            if (i < N) {
+                const double um = s_u[i], u0 = s_u[i + 1], ur = s_u[i + 2];
+                const double gi = a.G[(size_t)smp * N + i];
+                if (i == 0) {
+                    rhs = mu1 - u0;                                   // Dirichlet row
+                } else {
+                    // left element (i-1, i)
+                    const double wl = um + u0;
+                    lo = __builtin_fma(-mc.dt6, wl + u0, mc.aoff);
+                    const double tl = __builtin_fma(wl, u0 - um, -a.hfs[(size_t)smp * N + i - 1]);
+                    const double sl = tl * rcp(fmax(fabs(wl), 2.0e-10));
+                    double b = __builtin_fma(-mc.kap, sl, gi);
+                    if (i < N - 1) {
+                        const double wr = u0 + ur;
+                        up = __builtin_fma(mc.dt6, wr + u0, mc.aoff);
+                        di = __builtin_fma(mc.dt6, um - ur, mc.dd2);
+                        const double tr = __builtin_fma(wr, ur - u0, -a.hfs[(size_t)smp * N + i]);
+                        const double sr = tr * rcp(fmax(fabs(wr), 2.0e-10));
+                        b = __builtin_fma(mc.kap, sr, b);
+                    } else {
+                        di = __builtin_fma(mc.dt6, wl + u0, mc.dd1);
+                    }
+                    rhs = __builtin_fma(-lo, um, b);
+                    rhs = __builtin_fma(-di, u0, rhs);
+                    rhs = __builtin_fma(-up, ur, rhs);
+                }
+            }
+            s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = -rhs;  // [3] = R
+        }
+        __syncthreads();
+        // ---- MFMA contraction over this wave's rows -------------------------------------------
+        f64x4 acc[NT][NT];
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < NT; ++tb) acc[ta][tb] = f64x4{0.0, 0.0, 0.0, 0.0};
+        double qp[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) qp[t] = 0.0;
+        const bool rcol_lane = (c == r - 16 * (NT - 1));      // lane that carries column r (= R)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int i = rowbase + s;
+            const double lo = s_coef[i][0], di = s_coef[i][1], up = s_coef[i][2], R = s_coef[i][3];
+            const double ui = s_u[i + 1];
+            double Y[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double y = lo * frag[t][s];
+                y = __builtin_fma(di, frag[t][s + 1], y);
+                y = __builtin_fma(up, frag[t][s + 2], y);
+                Y[t] = y;
+                qp[t] = __builtin_fma(frag[t][s + 1], ui, qp[t]);
+            }
+            double Bf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) Bf[t] = Y[t];
+            Bf[NT - 1] = rcol_lane ? R : Bf[NT - 1];
+            if (a.proj == BG_PROJ_GALERKIN) {
+#pragma unroll
+                for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < NT; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[ta][s + 1], Bf[tb], acc[ta][tb], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                    for (int tb = ta; tb < NT; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[ta], Bf[tb], acc[ta][tb], 0, 0, 0);
+            }
+        }
+        // ---- cross-wave reduction through LDS, then write Ar | br | W^T u ----------------------
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s_red[w][16 * ta + g + 4 * k][16 * tb + c] = acc[ta][tb][k];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) s_q[w][g][16 * t + c] = qp[t];
+        __syncthreads();
+        const bool sym = a.proj != BG_PROJ_GALERKIN;
+        for (int e = tid; e < r * (r + 1); e += 256) {
+            const int row = e / (r + 1), col = e % (r + 1);
+            int rr = row, cc = col;
+            if (sym && col < r && (row >> 4) > (col >> 4)) { rr = col; cc = row; }   // mirror lower tiles
+            const double v = (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
+            if (col < r)
+                a.Ar[((size_t)smp * r + row) * r + col] = v;
+            else
+                a.br[(size_t)smp * r + row] = v;
+        }
+        if (a.wtu) {
+            for (int j = tid; j < r; j += 256) {
+                double v = 0.0;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) v += s_q[ww][gg][j];
+                a.wtu[(size_t)smp * r + j] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// bg_lu_solve: x = solve(A, sign * b), partial pivoting, one wavefront per system.
+//   lane i holds row i of [A | b]; rows are never moved: the pivot of step k is the
+//   not-yet-used lane with the largest |a[k]| (LAPACK gesv's choice up to ties in the
+//   top 32 bits), its row is broadcast with v_readlane.  reference: np.linalg.solve :767.
+// ------------------------------------------------------------------------------------
+struct LuArgs {
+    const double* A;      // [B][n][n]
+    const double* b;      // [B][n]
+    const int32_t* active;
+    double* x;            // [B][n]
+    int32_t* info;        // [B]  0 ok, k+1 = zero pivot at step k
+    double sign;
+    int n, B;
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    // DPP butterfly on 32-bit keys; result valid in lane 63, then broadcast
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true); v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true); v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true); v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true); v = v > t ? v : t;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(256) void lu_solve_kernel(LuArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int sys = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sys >= a.B) return;
+    if (a.active && a.active[sys] == 0) return;
+    const int n = a.n;
+    double row[NMAX + 1];
+    const double* Ap = a.A + (size_t)sys * n * n;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j)
+        row[j] = (lane < n && j < n) ? Ap[(size_t)lane * n + j] : ((lane == j) ? 1.0 : 0.0);
+    row[NMAX] = (lane < n) ? a.sign * a.b[(size_t)sys * n + lane] : 0.0;
+
+    bool used = false;        // this lane's row already served as a pivot row
+    int my_step = -1;         // elimination step at which it did
+    int info = 0;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        // pivot search on the high dword of |a[k]| (monotone for non-negative doubles)
+        unsigned key = used ? 0u : (((unsigned)__double2hiint(row[k]) & 0x7fffffffu) + 1u);
+        const unsigned best = wave_max_u32(key);
+        const unsigned long long m = __ballot(key == best && !used);
+        const int p = __builtin_ctzll(m);                       // lowest candidate lane
+        const double piv = readlane_f64(row[k], p);
+        if (piv == 0.0 && info == 0) info = k + 1;
+        const double rp = rcp(piv);
+        const bool is_p = lane == p;
+        const double mult = (used || is_p) ? 0.0 : row[k] * rp;
+#pragma unroll
+        for (int j = k + 1; j <= NMAX; ++j) row[j] = __builtin_fma(-mult, readlane_f64(row[j], p), row[j]);
+        if (is_p) { used = true; my_step = k; }
+    }
+    // back substitution, column oriented: the row that pivoted at step k holds U[k][*]
+    double xout = 0.0;
+#pragma unroll
+    for (int k = NMAX - 1; k >= 0; --k) {
+        const unsigned long long m = __ballot(my_step == k);
+        const int p = __builtin_ctzll(m);
+        const double xk = readlane_f64(row[NMAX], p) * rcp(readlane_f64(row[k], p));
+        row[NMAX] = (my_step < k) ? __builtin_fma(-row[k], xk, row[NMAX]) : row[NMAX];
+        xout = (lane == k) ? xk : xout;
+    }
+    if (lane < n) a.x[(size_t)sys * n + lane] = xout;
+    if (lane == 0 && a.info) a.info[sys] = info;
+}
+
+template <typename F>
+int dispatch_lu(int n, F&& f)
+{
+    if (n <= 8) return f(std::integral_constant<int, 8>{});
+    if (n <= 16) return f(std::integral_constant<int, 16>{});
+    if (n <= 24) return f(std::integral_constant<int, 24>{});
+    if (n <= 32) return f(std::integral_constant<int, 32>{});
+    if (n <= 40) return f(std::integral_constant<int, 40>{});
+    if (n <= 48) return f(std::integral_constant<int, 48>{});
+    if (n <= 64) return f(std::integral_constant<int, 64>{});
+    return BG_ERR_UNSUPPORTED_R;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bg_forcing_setup(int N, int B, const double* x, const double* mu2, double dt, double* fdt, double* hfs,
+                     void* stream)
+{
+    if (N < 2 || B < 0) return BG_ERR_BAD_ARG;
+    if (B == 0) return BG_OK;
+    if (!x || !mu2 || !fdt || !hfs || B > 65535) return BG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(forcing_setup_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, mu2, N,
+                       B, dt, fdt, hfs);
+    return check_launch_rom();
+}
+
+int bg_mass_rhs(int N, int B, const double* x, const double* un, const double* fdt, double* g, void* stream)
+{
+    if (N < 2 || B < 0) return BG_ERR_BAD_ARG;
+    if (B == 0) return BG_OK;
+    if (!x || !un || !fdt || !g || B > 65535) return BG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mass_rhs_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, un, fdt, N, B,
+                       g);
+    return check_launch_rom();
+}
+
+int bg_rom_max_n(void) { return 512; }
+int bg_rom_max_r(void) { return 47; }
+
+int bg_rom_reduce(int N, int B, int r, int projection, const double* x, const double* W, long long w_stride,
+                  const double* U, const double* G, const double* hfs, const double* mu1, double dt, double E,
+                  int supg, const int32_t* active, double* Ar, double* br, double* wtu, void* stream)
+{
+    if (N < 2 || B < 0 || r < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
+    if (projection != BG_PROJ_GALERKIN && projection != BG_PROJ_LSPG) return BG_ERR_PROJECTION;
+    if (N > 512) return BG_ERR_UNSUPPORTED_N;
+    if (r > 47) return BG_ERR_UNSUPPORTED_R;
+    if (B == 0) return BG_OK;
+    if (!x || !W || !U || !G || !hfs || !mu1 || !Ar || !br) return BG_ERR_BAD_ARG;
+    ReduceArgs a;
+    a.x = x; a.W = W; a.w_stride = w_stride; a.U = U; a.G = G; a.hfs = hfs; a.mu1 = mu1; a.active = active;
+    a.Ar = Ar; a.br = br; a.wtu = wtu; a.dt = dt; a.E = E; a.N = N; a.B = B; a.r = r; a.proj = projection;
+    a.supg = supg;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    const int grid = B < cus ? B : cus;
+    hipStream_t st = (hipStream_t)stream;
+    const int S = N <= 128 ? 8 : (N <= 256 ? 16 : 32);
+    const int NT = (r + 1 + 15) / 16;     // room for the extra column that carries R
+#define BG_LAUNCH_REDUCE(SV, NTV) hipLaunchKernelGGL((rom_reduce_kernel<SV, NTV>), dim3(grid), dim3(256), 0, st, a)
+    switch (S * 10 + NT) {
+        case 81: BG_LAUNCH_REDUCE(8, 1); break;
+        case 82: BG_LAUNCH_REDUCE(8, 2); break;
+        case 83: BG_LAUNCH_REDUCE(8, 3); break;
+        case 161: BG_LAUNCH_REDUCE(16, 1); break;
+        case 162: BG_LAUNCH_REDUCE(16, 2); break;
+        case 163: BG_LAUNCH_REDUCE(16, 3); break;
+        case 321: BG_LAUNCH_REDUCE(32, 1); break;
+        case 322: BG_LAUNCH_REDUCE(32, 2); break;
+        case 323: BG_LAUNCH_REDUCE(32, 3); break;
+        default: return BG_ERR_UNSUPPORTED_R;
+    }
+#undef BG_LAUNCH_REDUCE
+    return check_launch_rom();
+}
+
+int bg_lu_solve(int n, int B, const double* A, const double* b, double sign, const int32_t* active, double* x,
+                int32_t* info, void* stream)
+{
+    if (n < 1 || B < 0) return BG_ERR_BAD_ARG;
+    if (B == 0) return BG_OK;
+    if (!A || !b || !x) return BG_ERR_BAD_ARG;
+    LuArgs a{A, b, active, x, info, sign, n, B};
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_lu(n, [&](auto nc) {
+        constexpr int NMAX = decltype(nc)::value;
+        hipLaunchKernelGGL((lu_solve_kernel<NMAX>), dim3((B + 3) / 4), dim3(256), 0, st, a);
+        return check_launch_rom();
+    });
+}
+
+}  // extern "C"

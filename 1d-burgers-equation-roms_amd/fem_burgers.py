@@ -26,6 +26,7 @@ if _HERE not in sys.path:
 
 from burgers_hip import fom as _fom          # noqa: E402
 from burgers_hip import lib as _lib          # noqa: E402
+from burgers_hip import rom as _rom          # noqa: E402
 
 __all__ = ["FEMBurgers"]
 
@@ -81,4 +82,36 @@ class FEMBurgers:
         batched = self._batched(mu1, mu2)
         res = _fom.fom_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps), E=E,
                            tol=1e-6, max_it=20, supg=True)
+        return self._finish(res, batched)
+
+    # --------------------------------------------------------------- POD-Galerkin / LSPG
+    def pod_prom_burgers(self, At, nTimeSteps, u0, mu1, E, mu2, Phi, projection="Galerkin"):
+        """POD projection ROM (reference :709-785).  ``projection`` is "Galerkin" or "LSPG",
+        case-sensitive as in the reference; anything else raises ValueError."""
+        batched = self._batched(mu1, mu2)
+        res = _rom.pod_prom_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps),
+                                np.asarray(Phi, dtype=np.float64), projection=projection, E=E)
+        return self._finish(res, batched)
+
+    # ---------------------------------------------------------------- quadratic manifold
+    def pod_quadratic_manifold(self, At, nTimeSteps, u0, uxa, E, mu2, Phi, H, projection="LSPG",
+                               newton_tol=1e-6, newton_itmax=25):
+        """Quadratic-manifold PROM (reference :1081-1175); ``uxa`` is the left Dirichlet value."""
+        batched = self._batched(uxa, mu2)
+        res = _rom.quadratic_run(self.X, np.asarray(u0, dtype=np.float64), uxa, mu2, At, int(nTimeSteps),
+                                 np.asarray(Phi, dtype=np.float64), np.asarray(H, dtype=np.float64),
+                                 projection=projection, E=E, newton_tol=newton_tol, newton_itmax=newton_itmax)
+        if self.verbose and (res.flags != 0).any():
+            print("  Warning: Newton did not converge")
+        return self._finish(res, batched)
+
+    # --------------------------------------------------------------------------- POD-ANN
+    def pod_ann_prom(self, At, nTimeSteps, u0, mu1, E, mu2, U_p, U_s, model, projection="LSPG"):
+        """POD-ANN PROM (reference :1177-1251).  ``model`` is any torch.nn.Module mapping
+        (., n) -> (., nbar); it is borrowed and evaluated in float32 like the reference."""
+        import copy
+        batched = self._batched(mu1, mu2)
+        res = _rom.pod_ann_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps),
+                               np.asarray(U_p, dtype=np.float64), np.asarray(U_s, dtype=np.float64),
+                               copy.deepcopy(model), projection=projection, E=E)
         return self._finish(res, batched)

@@ -99,6 +99,49 @@ int bg_tridiag_solve(int N, int B, const double *lo, const double *di, const dou
  * --------------------------------------------------------------------------------- */
 int bg_transpose_batched(int B, int rows, int cols, const double *in, double *out, void *stream);
 
+/* =================================================================================
+ * Projection ROMs: one batched Picard / Gauss-Newton iteration is
+ *     bg_rom_reduce  ->  bg_lu_solve  ->  (family-specific update, host side GEMMs)
+ * ================================================================================= */
+
+/* Largest N / r the register-resident MFMA reduce kernel covers (N <= 512, r <= 47). */
+int bg_rom_max_n(void);
+int bg_rom_max_r(void);
+
+/* bg_forcing_setup -- per-sample load constants, once per run
+ *   reference: compute_forcing_vector FEM/fem_burgers.py:427-461 (the reference recomputes
+ *   it every iteration, :673) and the f_gp terms of compute_supg_term :556-558.
+ *   fdt[b][i] = dt * F_i(mu2_b);  hfs[b][e] = h_e * (f(gp1) + f(gp2)), hfs[b][N-1] = 0. */
+int bg_forcing_setup(int N, int B, const double *x, const double *mu2, double dt, double *fdt,
+                     double *hfs, void *stream);
+
+/* bg_mass_rhs -- g[b] = M u^n[b] + dt F[b], once per time step
+ *   reference: `M @ U[:, n] + At*F` at FEM/fem_burgers.py:683 / :746 / :1141 / :1214. */
+int bg_mass_rhs(int N, int B, const double *x, const double *un, const double *fdt, double *g,
+                void *stream);
+
+/* bg_rom_reduce -- fused assembly + projection of one iteration, fp64 MFMA
+ *   reference: FEM/fem_burgers.py:730-762 (pod_prom_burgers), :1134-1156
+ *   (pod_quadratic_manifold, supg = 0), :1203-1233 (pod_ann_prom).
+ *   W        basis or tangent, [N][r] row-major shared by all samples (w_stride = 0) or
+ *            [B][N][r] with w_stride = N*r elements
+ *   U        [B][N] current iterate u_k;  G from bg_mass_rhs;  hfs from bg_forcing_setup
+ *   active   [B] int32 or NULL: samples with 0 are skipped and their outputs left untouched
+ *   Ar       [B][r][r]: W^T A W (BG_PROJ_GALERKIN) or (A W)^T (A W) (BG_PROJ_LSPG)
+ *   br       [B][r]:    W^T R   or (A W)^T R,  R = A u_k - b
+ *   wtu      [B][r] or NULL: W^T u_k (the `Phi.T @ U0` of :770) */
+int bg_rom_reduce(int N, int B, int r, int projection, const double *x, const double *W,
+                  long long w_stride, const double *U, const double *G, const double *hfs,
+                  const double *mu1, double dt, double E, int supg, const int32_t *active,
+                  double *Ar, double *br, double *wtu, void *stream);
+
+/* bg_lu_solve -- x[b] = solve(A[b], sign * rhs[b]), partial pivoting, n <= 64
+ *   reference: np.linalg.solve(Ar, -br) at FEM/fem_burgers.py:767 / :1161 / :1237
+ *   (LAPACK gesv).  info[b] = 0, or k+1 when the pivot of step k is exactly zero
+ *   (numpy raises LinAlgError("Singular matrix") there). */
+int bg_lu_solve(int n, int B, const double *A, const double *rhs, double sign, const int32_t *active,
+                double *x, int32_t *info, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,207 @@
+"""GPU parity of the projection-ROM path (bg_rom_reduce, bg_lu_solve and the three batched
+time-steppers) against the oracle and the golden fixtures.  fp64 parts: rel-L2 <= 1e-10;
+POD-ANN is fp32-limited by the reference's own float32 MLP evaluation."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, mesh, rel_l2
+from oracle import burgers_ref as br
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+@pytest.mark.parametrize("n", [1, 5, 8, 21, 40, 47, 64])
+def test_lu_solve_vs_numpy(hip, n):
+    from burgers_hip import rom
+    rng = np.random.default_rng(n)
+    B = 37
+    A = rng.standard_normal((B, n, n)) + 0.1 * np.eye(n)        # needs pivoting
+    A[3] = A[3][::-1].copy()                                     # tiny leading pivots
+    b = rng.standard_normal((B, n))
+    x, info = rom.lu_solve(_dev(A), _dev(b), -1.0)
+    torch.cuda.synchronize()
+    ref = np.linalg.solve(A, -b[..., None])[..., 0]
+    assert (info.cpu().numpy() == 0).all()
+    for i in range(B):
+        cond = np.linalg.cond(A[i])
+        assert rel_l2(x[i].cpu().numpy(), ref[i]) < 1e-13 * max(10.0, cond), (n, i)
+    # zero matrix -> singular, reported (numpy raises LinAlgError there)
+    A0 = np.zeros((2, n, n)); A0[1] = np.eye(n)
+    _, info = rom.lu_solve(_dev(A0), _dev(np.ones((2, n))), 1.0)
+    assert info.cpu().numpy()[0] != 0 and info.cpu().numpy()[1] == 0
+
+
+@pytest.mark.parametrize("N,r,shared", [(512, 40, True), (512, 21, False), (512, 5, False), (256, 16, True),
+                                        (300, 33, True), (96, 7, False), (512, 47, True), (128, 40, False)])
+def test_rom_reduce_vs_oracle(hip, N, r, shared):
+    from burgers_hip import rom
+    rng = np.random.default_rng(N * 100 + r)
+    X, _ = mesh(N)
+    B = 7
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    dt, E = 0.05, 0.01
+    U = 1.0 + 4.0 * rng.random((B, N)); Un = 1.0 + 4.0 * rng.random((B, N))
+    W = rng.standard_normal((N, r)) if shared else rng.standard_normal((B, N, r))
+    c = rom._setup(X, Un, mu1, mu2, dt, E, None)
+    G = torch.empty((B, N), dtype=torch.float64, device="cuda")
+    rom._mass_rhs(c, _dev(Un), G)
+    M3, K3 = br.mass_tridiag(X), br.diffusion_tridiag(X)
+    for supg in (True, False):
+        for pname, proj in (("galerkin", 0), ("lspg", 1)):
+            Ar = torch.zeros((B, r, r), dtype=torch.float64, device="cuda")
+            brr = torch.zeros((B, r), dtype=torch.float64, device="cuda")
+            wtu = torch.zeros((B, r), dtype=torch.float64, device="cuda")
+            active = torch.ones(B, dtype=torch.int32, device="cuda"); active[2] = 0
+            rom.rom_reduce(c, _dev(W), _dev(U), G, proj, supg, active, Ar, brr, wtu)
+            torch.cuda.synchronize()
+            Ar, brr, wtu = Ar.cpu().numpy(), brr.cpu().numpy(), wtu.cpu().numpy()
+            for b in range(B):
+                if b == 2:
+                    assert not Ar[b].any() and not brr[b].any()        # skipped sample untouched
+                    continue
+                Wb = W if shared else W[b]
+                lo, di, up = br.system_tridiag(M3, K3, br.convection_tridiag(X, U[b]), dt, E)
+                bb = br.tridiag_matvec(*M3, Un[b]) + dt * br.forcing_vector(X, mu2[b])
+                if supg:
+                    bb = bb - dt * br.supg_term(X, U[b], mu2[b])
+                bb[0] = mu1[b]
+                R = br.tridiag_matvec(lo, di, up, U[b]) - bb
+                Ar_ref, br_ref = br._reduce(lo, di, up, R, Wb, pname)
+                assert rel_l2(Ar[b], Ar_ref) < 1e-13, (pname, supg, b)
+                assert rel_l2(brr[b], br_ref) < 1e-12, (pname, supg, b)
+                assert rel_l2(wtu[b], Wb.T @ U[b]) < 1e-13
+
+
+def test_pod_prom_golden_and_live(hip):
+    from burgers_hip import rom
+    g = load_golden("committed_pod_r40.npz")
+    live = load_golden("pod_live_r40.npz")
+    X, _ = mesh(512)
+    for tag, proj in (("galerkin", "Galerkin"), ("lspg", "LSPG")):
+        res = rom.pod_prom_run(X, np.ones(512), [4.75, float(live["mu1"])], [0.02, float(live["mu2"])], 0.05, 12,
+                               g["Phi"], projection=proj)
+        torch.cuda.synchronize()
+        h = res.hist.cpu().numpy(); it = res.iters.cpu().numpy()
+        assert rel_l2(h[0].T, g["first13_" + tag]) < TOL                # reference's committed .npy
+        nT = int(live["nT"])
+        assert rel_l2(h[1].T[:, :nT + 1], live["U_" + proj]) < TOL       # live reference run
+        assert np.array_equal(it[1][:nT], live["iters_" + proj])
+    with pytest.raises(ValueError):
+        rom.pod_prom_run(X, np.ones(512), 4.75, 0.02, 0.05, 1, g["Phi"], projection="lspg")
+
+
+def test_pod_prom_batch_vs_oracle(hip):
+    from burgers_hip import rom
+    g = load_golden("committed_pod_r40.npz")
+    rng = np.random.default_rng(3)
+    X, _ = mesh(512)
+    B = 12
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    for proj in ("Galerkin", "LSPG"):
+        res = rom.pod_prom_run(X, np.ones(512), mu1, mu2, 0.05, 25, g["Phi"], projection=proj)
+        torch.cuda.synchronize()
+        h = res.hist.cpu().numpy(); it = res.iters.cpu().numpy()
+        for b in range(B):
+            U, ito = br.pod_prom_burgers(X, 0.05, 25, np.ones(512), mu1[b], 0.0, mu2[b], g["Phi"], projection=proj,
+                                         return_iters=True)
+            assert rel_l2(h[b].T, U) < TOL, (proj, b)
+            assert np.array_equal(it[b], ito), (proj, b)
+
+
+def test_quadratic_golden_and_live(hip):
+    from burgers_hip import rom
+    c = load_golden("committed_quadratic_n21.npz")
+    live = load_golden("quadratic_live_n21.npz")
+    X, _ = mesh(512)
+    res = rom.quadratic_run(X, np.ones(512), float(c["mu1"]), float(c["mu2"]), 0.05, 6, c["Phi"], c["H"])
+    torch.cuda.synchronize()
+    assert rel_l2(res.hist[0].cpu().numpy().T, c["first7"]) < TOL       # committed quadratic PROM output
+    for proj in ("Galerkin", "LSPG"):
+        res = rom.quadratic_run(X, np.ones(512), float(live["mu1"]), float(live["mu2"]), float(live["At"]),
+                                int(live["nT"]), c["Phi"], c["H"], projection=proj)
+        torch.cuda.synchronize()
+        assert rel_l2(res.hist[0].cpu().numpy().T, live["U_" + proj]) < TOL
+        assert np.array_equal(res.iters[0].cpu().numpy(), live["iters_" + proj])
+    with pytest.raises(ValueError):
+        rom.quadratic_run(X, np.ones(512), 4.5, 0.02, 0.05, 1, c["Phi"], c["H"], projection="petrov")
+
+
+def test_quadratic_batch_vs_oracle(hip):
+    from burgers_hip import rom
+    c = load_golden("committed_quadratic_n21.npz")
+    rng = np.random.default_rng(5)
+    X, _ = mesh(512)
+    B = 6
+    mu1 = rng.uniform(4.4, 5.3, B); mu2 = rng.uniform(0.017, 0.028, B)
+    res = rom.quadratic_run(X, np.ones(512), mu1, mu2, 0.05, 10, c["Phi"], c["H"])
+    torch.cuda.synchronize()
+    for b in range(B):
+        U, ito = br.pod_quadratic_manifold(X, 0.05, 10, np.ones(512), mu1[b], 0.0, mu2[b], c["Phi"], c["H"],
+                                           return_iters=True)
+        assert rel_l2(res.hist[b].cpu().numpy().T, U) < TOL
+        assert np.array_equal(res.iters[b].cpu().numpy(), ito)
+
+
+def _ann_model(g):
+    import torch.nn as nn
+    dims = [5, 32, 64, 128, 256, 256, 91]
+    layers = []
+    for i in range(6):
+        lin = nn.Linear(dims[i], dims[i + 1])
+        with torch.no_grad():
+            lin.weight.copy_(torch.from_numpy(g[f"W{i}"])); lin.bias.copy_(torch.from_numpy(g[f"b{i}"]))
+        layers.append(lin)
+        if i < 5:
+            layers.append(nn.ELU())
+    return nn.Sequential(*layers).eval()
+
+
+def test_pod_ann_live_reference(hip):
+    """The reference evaluates the MLP and its autograd Jacobian in float32, so parity is
+    fp32-limited: tolerance 5e-6 (same bound the oracle meets against the live reference)."""
+    from burgers_hip import rom
+    g = load_golden("ann_n5.npz")
+    model = _ann_model(g)
+    X, _ = mesh(512)
+    # forward / Jacobian vectors recorded from the reference's torch model
+    q = _dev(g["qp"]).float()
+    with torch.no_grad():
+        fwd = model.cuda()(q).cpu().numpy()
+        jac = rom.ann_jacobian(model, q).cpu().numpy()
+    assert np.abs(fwd - g["fwd"]).max() < 2e-5 * max(1.0, np.abs(g["fwd"]).max())
+    assert np.abs(jac - g["jac"]).max() < 2e-4 * max(1.0, np.abs(g["jac"]).max())
+    res = rom.pod_ann_run(X, np.ones(512), float(g["mu1"]), float(g["mu2"]), float(g["At"]), int(g["nT"]),
+                          g["U_p"], g["U_s"], model)
+    torch.cuda.synchronize()
+    assert rel_l2(res.hist[0].cpu().numpy().T, g["U"]) < 5e-6
+    Ws = [g[f"W{i}"] for i in range(6)]; bs = [g[f"b{i}"] for i in range(6)]
+    Uo = br.pod_ann_prom(X, float(g["At"]), int(g["nT"]), np.ones(512), float(g["mu1"]), 0.0, float(g["mu2"]),
+                         g["U_p"], g["U_s"], Ws, bs)
+    assert rel_l2(res.hist[0].cpu().numpy().T, Uo) < 5e-6
+
+
+def test_facade_rom_methods(hip):
+    """Reference call patterns: POD/Results_thesis/prom_pod.py:58, quadratic_prom_simulation.py:49-55,
+    POD-ANN/pod_ann_prom_burgers.py:81."""
+    from fem_burgers import FEMBurgers
+    X, T = mesh(512)
+    fem = FEMBurgers(X, T)
+    g = load_golden("committed_pod_r40.npz")
+    U = fem.pod_prom_burgers(0.05, 12, np.ones(512), 4.75, 0.0, 0.02, g["Phi"], projection="LSPG")
+    assert U.shape == (512, 13) and rel_l2(U, g["first13_lspg"]) < TOL
+    with pytest.raises(ValueError):
+        fem.pod_prom_burgers(0.05, 1, np.ones(512), 4.75, 0.0, 0.02, g["Phi"], projection="Petrov")
+    c = load_golden("committed_quadratic_n21.npz")
+    Hf = np.asfortranarray(c["H"])                       # the committed H.npy is Fortran-ordered
+    U = fem.pod_quadratic_manifold(0.05, 6, np.ones(512), float(c["mu1"]), 0.0, float(c["mu2"]), c["Phi"], Hf,
+                                   projection="LSPG")
+    assert rel_l2(U, c["first7"]) < TOL
+    a = load_golden("ann_n5.npz")
+    U = fem.pod_ann_prom(0.05, 4, np.ones(512), 4.56, 0.0, 0.019, a["U_p"], a["U_s"], _ann_model(a))
+    assert U.shape == (512, 5) and rel_l2(U, a["U"]) < 5e-6
