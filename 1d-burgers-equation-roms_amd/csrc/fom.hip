@@ -83,8 +83,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void fom_fused_kernel(FomArgs
                 nd = __builtin_fma(rhs[j], rhs[j], nd);
                 nu = __builtin_fma(u[j], u[j], nu);
             }
-            nd = wave_sum(nd);
-            nu = wave_sum(nu);
+            wave_sum2(nd, nu, nd, nu);
             ++k;
             // reference: error = ||dU|| / ||U1||; continue while error > tol and k < cap.
             // NaN compares false and ends the loop, as in the reference.

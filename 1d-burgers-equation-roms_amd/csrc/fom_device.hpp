@@ -13,6 +13,11 @@
 #pragma once
 #include "wave_ops.hpp"
 
+// reciprocal used inside the Picard iteration (see wave_ops.hpp: rcp = 2 Newton steps, rcp1 = 1)
+#ifndef BG_RCP
+#define BG_RCP rcp1
+#endif
+
 namespace bg {
 
 constexpr double GP_A = 0.78867513459481287;  // (1 + 1/sqrt(3)) / 2
@@ -115,7 +120,7 @@ __device__ __forceinline__ void assemble(const MeshConst& c, int N, int row0, do
         if (j + 1 < R) lo[j + 1] = __builtin_fma(-c.dt6, w + ur, c.aoff);
         const double mx = fmax(fabs(w), 2.0e-10);
         const double t = __builtin_fma(w, dif, -hfs[j]);
-        se[j] = t * rcp(mx);
+        se[j] = t * BG_RCP(mx);
     }
     lo[0] = __builtin_fma(-c.dt6, __builtin_fma(2.0, u[0], uL), c.aoff);
     const double seL = from_lane_below(se[R - 1]);
@@ -158,6 +163,27 @@ __device__ __forceinline__ void assemble(const MeshConst& c, int N, int row0, do
     }
 }
 
+// One PCR step on normalised equations A x[j-s] + x[j] + C x[j+s] = D; neighbours come from
+// DPP moves (CTRL_DN: from lower lanes, CTRL_UP: from higher lanes, applied REPS times, zero
+// filled out of range, which is the identity equation).  LAST skips the A/C update.
+template <int CTRL_DN, int CTRL_UP, int REPS, bool LAST>
+__device__ __forceinline__ void pcr_step(double& A, double& C, double& D)
+{
+    const double Dm = dpp_shift<CTRL_DN, REPS>(D), Dp = dpp_shift<CTRL_UP, REPS>(D);
+    const double Cm = dpp_shift<CTRL_DN, REPS>(C), Ap = dpp_shift<CTRL_UP, REPS>(A);
+    double Bn = __builtin_fma(-Cm, A, 1.0);
+    Bn = __builtin_fma(-Ap, C, Bn);
+    double Dn = __builtin_fma(-Dm, A, D);
+    Dn = __builtin_fma(-Dp, C, Dn);
+    const double rb = BG_RCP(Bn);
+    D = Dn * rb;
+    if (!LAST) {
+        const double Am = dpp_shift<CTRL_DN, REPS>(A), Cp = dpp_shift<CTRL_UP, REPS>(C);
+        A = -(Am * A) * rb;
+        C = -(Cp * C) * rb;
+    }
+}
+
 // Pivot-free tridiagonal solve across the wave (Wang partition + PCR on the 64
 // interface unknowns).  In: lo/di/up/rhs.  Out: solution in rhs.  lo, di are clobbered.
 template <int R>
@@ -168,18 +194,18 @@ __device__ __forceinline__ void tridiag_solve(double (&lo)[R], double (&di)[R], 
     double A, C, D;           // normalised interface equation: A x[p-1] + x[p] + C x[p+1] = D
     double gs[R > 1 ? R : 1];
     if constexpr (R == 1) {
-        const double rb = rcp(di[0]);
+        const double rb = BG_RCP(di[0]);
         A = lo[0] * rb; C = up[0] * rb; D = rhs[0] * rb;
     } else {
         // phase 1: eliminate sub-diagonal downwards; lo[] becomes the left spike f[],
         // di[] becomes 1/pivot
         double dp = di[0];
-        di[0] = rcp(dp);
+        di[0] = BG_RCP(dp);
 #pragma unroll
         for (int j = 1; j < R; ++j) {
             const double m = lo[j] * di[j - 1];
             dp = __builtin_fma(-m, up[j - 1], di[j]);
-            di[j] = rcp(dp);
+            di[j] = BG_RCP(dp);
             rhs[j] = __builtin_fma(-m, rhs[j - 1], rhs[j]);
             lo[j] = -m * lo[j - 1];
         }
@@ -198,30 +224,27 @@ __device__ __forceinline__ void tridiag_solve(double (&lo)[R], double (&di)[R], 
         const double R0 = from_lane_above(rhs[0] * di[0]);
         const double ul = up[R - 1];
         const double B = __builtin_fma(-ul, F0, dp);
-        const double rb = rcp(B);
+        const double rb = BG_RCP(B);
         A = lo[R - 1] * rb;
         C = -(ul * G0) * rb;
         D = __builtin_fma(-ul, R0, rhs[R - 1]) * rb;
     }
-    // PCR over the 64 interface equations; neighbours wrap mod 64, which is exact
-    // because A == 0 on lanes < stride and C == 0 on lanes >= 64 - stride.
-#pragma unroll
-    for (int s = 1; s < 64; s *= 2) {
-        const int below = ((lane - s) & 63) << 2, above = ((lane + s) & 63) << 2;
-        const double Dm = from_lane_rot(D, below), Dp = from_lane_rot(D, above);
-        const double Cm = from_lane_rot(C, below), Ap = from_lane_rot(A, above);
-        double Bn = __builtin_fma(-Cm, A, 1.0);
-        Bn = __builtin_fma(-Ap, C, Bn);
-        double Dn = __builtin_fma(-Dm, A, D);
-        Dn = __builtin_fma(-Dp, C, Dn);
-        const double rb = rcp(Bn);
-        D = Dn * rb;
-        if (s < 32) {
-            const double Am = from_lane_rot(A, below), Cp = from_lane_rot(C, above);
-            A = -(Am * A) * rb;
-            C = -(Cp * C) * rb;
-        }
+    // PCR over the 64 interface equations.  ds_bpermute costs ~24 cycles per dword on gfx950
+    // against ~6 for a DPP move, so: strides 1 and 2 use wave_shr/wave_shl:1 (once / twice, zero
+    // filled), then ONE lane transpose (lane' = 16*(j&3) + (j>>2)) turns the four interleaved
+    // stride-4 systems into the four 16-lane DPP rows, where strides 4,8,16,32 are row_shr/shl
+    // 1,2,4,8 with zero fill at the row ends (= the system ends).
+    pcr_step<0x138, 0x130, 1, false>(A, C, D);
+    pcr_step<0x138, 0x130, 2, false>(A, C, D);
+    {
+        const int src = ((4 * (lane & 15) + (lane >> 4)) << 2);
+        A = from_lane_rot(A, src); C = from_lane_rot(C, src); D = from_lane_rot(D, src);
     }
+    pcr_step<0x111, 0x101, 1, false>(A, C, D);
+    pcr_step<0x112, 0x102, 1, false>(A, C, D);
+    pcr_step<0x114, 0x104, 1, false>(A, C, D);
+    pcr_step<0x118, 0x108, 1, true>(A, C, D);
+    D = from_lane_rot(D, (16 * (lane & 3) + (lane >> 2)) << 2);
     const double X = D;                      // this lane's last unknown
     if constexpr (R == 1) {
         rhs[0] = X;
