@@ -56,6 +56,15 @@ _SIGNATURES = {
                                      c_double_p, ctypes.c_longlong, c_double_p, c_double_p, c_double_p,
                                      c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_int_p,
                                      c_double_p, c_double_p, c_double_p, ctypes.c_void_p]),
+    "bg_rom_reduce_lifted": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
+                                            c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                            c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_int_p,
+                                            c_double_p, c_double_p, c_double_p, ctypes.c_void_p]),
+    "bg_rom_lift": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                   c_int_p, c_double_p, ctypes.c_void_p]),
+    "bg_lu_solve_update": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int,
+                                          c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_int,
+                                          c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
     "bg_lu_solve": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_double,
                                    c_int_p, c_double_p, c_int_p, ctypes.c_void_p]),
 }

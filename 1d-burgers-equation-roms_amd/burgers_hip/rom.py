@@ -113,6 +113,62 @@ def lu_solve(A, b, sign=1.0, active=None, x=None, info=None):
     return x, info
 
 
+def rom_reduce_lifted(c, Phi, q, U, G, proj, supg, active, Ar, br, wtu):
+    """bg_rom_reduce with u = Phi q formed in-kernel (and stored to U)."""
+    r = Phi.shape[1]
+    with torch.cuda.device(c.device):
+        rc = c.L.bg_rom_reduce_lifted(c.N, c.B, r, proj, _lib.ptr(c.X), _lib.ptr(Phi), _lib.ptr(q), _lib.ptr(U),
+                                      _lib.ptr(G), _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, 1 if supg else 0,
+                                      _lib.ptr(active) if active is not None else None, _lib.ptr(Ar), _lib.ptr(br),
+                                      _lib.ptr(wtu) if wtu is not None else None, c.stream())
+    if rc == _lib.BG_ERR_UNSUPPORTED_R:
+        raise NotImplementedError(f"ROM kernels cover r <= {c.L.bg_rom_max_r()} (got {r})")
+    _lib.check(rc, "bg_rom_reduce_lifted")
+
+
+def rom_lift(c, Phi, q, U, active=None):
+    with torch.cuda.device(c.device):
+        rc = c.L.bg_rom_lift(c.N, c.B, Phi.shape[1], _lib.ptr(c.X), _lib.ptr(Phi), _lib.ptr(q),
+                             _lib.ptr(active) if active is not None else None, _lib.ptr(U), c.stream())
+    _lib.check(rc, "bg_rom_lift")
+
+
+class _IterState:
+    """Per-time-step bookkeeping that lives on the device; one 8-byte readback per iteration."""
+
+    def __init__(self, c, n):
+        i32 = dict(dtype=torch.int32, device=c.device)
+        self.c = c
+        self.active = torch.ones((c.B,), **i32)
+        self.k = torch.zeros((c.B,), **i32)
+        self.flags = torch.zeros((c.B,), **i32)
+        self.info = torch.zeros((c.B,), **i32)
+        self.counter = torch.zeros((2,), **i32)
+        self.dq = torch.zeros((c.B, n), dtype=torch.float64, device=c.device)
+
+    def begin_step(self):
+        self.active.fill_(1)
+        self.k.zero_()
+
+    def solve_update(self, mode, Ar, br, wtu, q, tol, max_it):
+        """dq = solve(Ar, -br); q, iteration counters and the active mask updated on the device.
+        Returns the number of samples that need another iteration."""
+        c = self.c
+        self.counter.zero_()
+        with torch.cuda.device(c.device):
+            rc = c.L.bg_lu_solve_update(q.shape[1], c.B, _lib.ptr(Ar), _lib.ptr(br), mode,
+                                        _lib.ptr(wtu) if wtu is not None else None, _lib.ptr(q), _lib.ptr(self.dq),
+                                        float(tol), int(max_it), _lib.ptr(self.active), _lib.ptr(self.k),
+                                        _lib.ptr(self.flags), _lib.ptr(self.counter), _lib.ptr(self.info), c.stream())
+        if rc == _lib.BG_ERR_UNSUPPORTED_R:
+            raise NotImplementedError("bg_lu_solve covers n <= 64")
+        _lib.check(rc, "bg_lu_solve_update")
+        n_active, n_singular = self.counter.cpu().tolist()
+        if n_singular:
+            raise SingularReducedSystem("Singular matrix")
+        return n_active
+
+
 def _poll(active, info):
     """One host readback per batched iteration: (#active samples, any singular pivot)."""
     s = torch.stack([active.sum(), (info != 0).sum().to(active.dtype)]).cpu()
@@ -150,29 +206,26 @@ def pod_prom_run(X, u0, mu1, mu2, dt, nsteps, Phi, projection="Galerkin", E=0.0,
     r = Phid.shape[1]
     PhiT = Phid.t().contiguous()
     hist, iters, flags = _alloc_hist(c, nsteps)
-    Ar, br, wtu, dq, info, G = _workspace(c, r)
+    Ar, br, wtu, _, _, G = _workspace(c, r)
+    st = _IterState(c, r)
+    q = torch.zeros((c.B, r), dtype=torch.float64, device=c.device)
     U0 = c.u0.clone()
     for n in range(nsteps):
         _mass_rhs(c, U0, G)
-        active = torch.ones((c.B,), dtype=torch.int32, device=c.device)
-        k = torch.zeros_like(active)
+        st.begin_step()
+        first = n == 0                      # u0 is not in span(Phi): the very first assembly reads it from HBM
         while True:
-            rom_reduce(c, Phid, U0, G, proj, True, active, Ar, br, wtu)
-            lu_solve(Ar, br, -1.0, active, dq, info)
-            q = wtu + dq                                   # q = Phi^T U0 + dq      (:770)
-            U1 = q @ PhiT                                  # U1 = Phi q             (:773)
-            err = torch.linalg.vector_norm(dq, dim=1) / torch.linalg.vector_norm(q, dim=1)
-            act = active.bool()
-            U0 = torch.where(act[:, None], U1, U0)
-            k += active
-            nonfin = act & ~torch.isfinite(err)
-            flags |= nonfin.to(torch.int32) * _lib.BG_FLAG_NONFINITE
-            active = (act & (err > tol) & (k < max_it)).to(torch.int32)
-            if _poll(active, info) == 0:
+            if first:
+                rom_reduce(c, Phid, U0, G, proj, True, st.active, Ar, br, wtu)
+                first = False
+            else:                           # u_k = Phi q formed in-kernel                 (:773)
+                rom_reduce_lifted(c, Phid, q, U0, G, proj, True, st.active, Ar, br, wtu)
+            if st.solve_update(1, Ar, br, wtu, q, tol, max_it) == 0:     # q = Phi^T U0 + dq (:767-776)
                 break
-        flags |= (k >= max_it).to(torch.int32) * _lib.BG_FLAG_HIT_CAP
-        iters[:, n] = k
+        rom_lift(c, Phid, q, U0)            # U[:, n+1] = Phi q                            (:779)
+        iters[:, n] = st.k
         hist[:, n + 1] = U0
+    flags |= st.flags
     return FomResult(hist, iters, flags)
 
 
@@ -211,31 +264,26 @@ def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0,
         return q @ PhiT + (q[:, I] * q[:, J]) @ HT
 
     hist, iters, flags = _alloc_hist(c, nsteps)
-    Ar, br, _, dq, info, G = _workspace(c, n)
+    Ar, br, _, _, _, G = _workspace(c, n)
+    st = _IterState(c, n)
+    H3t = H3.t().contiguous()
     Un = c.u0.clone()
     for m in range(nsteps):
         _mass_rhs(c, Un, G)
-        q = Un @ Phid                                        # first guess            (:1129)
-        u = decode(q)
-        active = torch.ones((c.B,), dtype=torch.int32, device=c.device)
-        k = torch.zeros_like(active)
-        for it in range(newton_itmax):
-            T = (Phid.reshape(1, c.N, n) + (q @ H3.t()).reshape(c.B, c.N, n)).contiguous()
-            rom_reduce(c, T, u, G, proj, False, active, Ar, br, None)
-            lu_solve(Ar, br, -1.0, active, dq, info)
-            act = active.bool()
-            qn = q + dq
-            q = torch.where(act[:, None], qn, q)
-            u = torch.where(act[:, None], decode(q), u)
-            rel = torch.linalg.vector_norm(dq, dim=1) / torch.clamp(torch.linalg.vector_norm(q, dim=1), min=1e-14)
-            k += active
-            active = (act & ~(rel < newton_tol)).to(torch.int32)       # `if rel < tol: break` (:1169)
-            if _poll(active, info) == 0:
+        q = (Un @ Phid).contiguous()                         # first guess            (:1129)
+        u = decode(q).contiguous()
+        st.begin_step()
+        while True:
+            T = (Phid.reshape(1, c.N, n) + (q @ H3t).reshape(c.B, c.N, n)).contiguous()
+            rom_reduce(c, T, u, G, proj, False, st.active, Ar, br, None)
+            left = st.solve_update(2, Ar, br, None, q, newton_tol, newton_itmax)     # q += dq (:1161-1169)
+            u = decode(q).contiguous()                       # inactive samples keep their q, hence their u
+            if left == 0:
                 break
-        flags |= active * _lib.BG_FLAG_HIT_CAP                         # "Newton did not converge" (:1171)
-        iters[:, m] = k
+        iters[:, m] = st.k
         hist[:, m + 1] = u
         Un = u
+    flags |= st.flags                                        # HIT_CAP = "Newton did not converge" (:1171)
     return FomResult(hist, iters, flags)
 
 
@@ -261,31 +309,25 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
     UpT, UsT = Up.t().contiguous(), Us.t().contiguous()
     model = model.to(device=c.device, dtype=ann_dtype)
     hist, iters, flags = _alloc_hist(c, nsteps)
-    Ar, br, _, dq, info, G = _workspace(c, n)
+    Ar, br, _, _, _, G = _workspace(c, n)
+    st = _IterState(c, n)
     U0 = c.u0.clone()
     for nt in range(nsteps):
         _mass_rhs(c, U0, G)
-        qp = U0 @ Up                                                       # (:1197)
-        active = torch.ones((c.B,), dtype=torch.int32, device=c.device)
-        k = torch.zeros_like(active)
+        qp = (U0 @ Up).contiguous()                                         # (:1197)
+        st.begin_step()
         while True:
             with torch.no_grad():
                 dN = ann_jacobian(model, qp.to(ann_dtype)).to(torch.float64)    # (B, nbar, n)
             dD = (Up.unsqueeze(0) + torch.matmul(Us, dN)).contiguous()      # U_p + U_s dN        (:1224)
-            rom_reduce(c, dD, U0, G, proj, True, active, Ar, br, None)
-            lu_solve(Ar, br, -1.0, active, dq, info)
-            act = active.bool()
-            qp = torch.where(act[:, None], qp + dq, qp)
+            rom_reduce(c, dD, U0, G, proj, True, st.active, Ar, br, None)
+            left = st.solve_update(3, Ar, br, None, qp, tol, max_it)        # q_p += dq           (:1237-1244)
             with torch.no_grad():
                 qs = model(qp.to(ann_dtype)).to(torch.float64)
-            U1 = qp @ UpT + qs @ UsT                                        # (:1242)
-            U0 = torch.where(act[:, None], U1, U0)
-            err = torch.linalg.vector_norm(dq, dim=1) / (torch.linalg.vector_norm(qp, dim=1) + 1e-14)
-            k += active
-            active = (act & (err > tol) & (k < max_it)).to(torch.int32)
-            if _poll(active, info) == 0:
+            U0 = (qp @ UpT + qs @ UsT).contiguous()                         # (:1242)
+            if left == 0:
                 break
-        flags |= (k >= max_it).to(torch.int32) * _lib.BG_FLAG_HIT_CAP
-        iters[:, nt] = k
+        iters[:, nt] = st.k
         hist[:, nt + 1] = U0
+    flags |= st.flags
     return FomResult(hist, iters, flags)

@@ -101,8 +101,10 @@ struct ReduceArgs {
     double* Ar;              // [B][r][r]
     double* br;              // [B][r]
     double* wtu;             // [B][r]  W^T u  (null = skip)
+    const double* q_in;      // [B][r] or null: if given, u = W q is formed here and stored to Uout
+    double* Uout;            // [B][N] (only with q_in)
     double dt, E;
-    int N, B, r, proj, supg;
+    int N, B, r, proj, supg, lift_only;
 };
 
 template <int S, int NT>
@@ -141,13 +143,39 @@ __global__ __launch_bounds__(256, 1) void rom_reduce_kernel(ReduceArgs a)
             }
             have_frags = true;
         }
-        // ---- stage u, assemble the tridiagonal system into LDS ------------------------------
-        const double* up_ = a.U + (size_t)smp * N;
-        for (int i = tid; i < NPAD + 2; i += 256) {
-            const int gi = i - 1;
-            s_u[i] = (gi >= 0 && gi < N) ? up_[gi] : 0.0;
+        // ---- stage u (from HBM, or lifted u = W q from the register-resident basis) ----------
+        if (a.q_in) {
+            double qv[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = 16 * t + c;
+                qv[t] = col < r ? a.q_in[(size_t)smp * r + col] : 0.0;
+            }
+            if (tid == 0) { s_u[0] = 0.0; s_u[NPAD + 1] = 0.0; }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                double p = 0.0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) p = __builtin_fma(frag[t][s + 1], qv[t], p);
+                p += dpp_mov<0x111>(p);            // sum over the 16 lanes of the DPP row
+                p += dpp_mov<0x112>(p);
+                p += dpp_mov<0x114>(p);
+                p += dpp_mov<0x118>(p);
+                if (c == 15) {
+                    const int i = rowbase + s;
+                    s_u[i + 1] = p;
+                    if (i < N) a.Uout[(size_t)smp * N + i] = p;
+                }
+            }
+        } else {
+            const double* up_ = a.U + (size_t)smp * N;
+            for (int i = tid; i < NPAD + 2; i += 256) {
+                const int gi = i - 1;
+                s_u[i] = (gi >= 0 && gi < N) ? up_[gi] : 0.0;
+            }
         }
         __syncthreads();
+        if (a.lift_only) continue;           // workgroup-uniform
         const double mu1 = a.mu1[smp];
         for (int i = tid; i < NPAD; i += 256) {
             double lo = 0.0, di = 1.0, up = 0.0, rhs = 0.0;
@@ -272,6 +300,15 @@ struct LuArgs {
     int32_t* info;        // [B]  0 ok, k+1 = zero pivot at step k
     double sign;
     int n, B;
+    // fused iteration update (mode != 0): see bg_lu_solve_update
+    int mode, max_it;
+    double tol;
+    const double* wtu;    // [B][n]  (mode 1)
+    double* q;            // [B][n]  in/out
+    int32_t* active_io;   // [B]
+    int32_t* iters;       // [B]
+    int32_t* flags;       // [B]
+    int32_t* counter;     // [1]  number of samples still active after this call
 };
 
 __device__ __forceinline__ double readlane_f64(double v, int srclane)
@@ -301,6 +338,7 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(LuArgs a)
     const int sys = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (sys >= a.B) return;
     if (a.active && a.active[sys] == 0) return;
+    if (a.mode != 0 && a.active_io[sys] == 0) return;
     const int n = a.n;
     double row[NMAX + 1];
     const double* Ap = a.A + (size_t)sys * n * n;
@@ -339,7 +377,35 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(LuArgs a)
         xout = (lane == k) ? xk : xout;
     }
     if (lane < n) a.x[(size_t)sys * n + lane] = xout;
-    if (lane == 0 && a.info) a.info[sys] = info;
+    if (lane == 0 && a.info && info) a.info[sys] = info;
+    if (a.mode != 0) {
+        if (lane == 0 && info) atomicAdd(a.counter + 1, 1);
+        // reference updates: POD  q = Phi^T U0 + dq, err = |dq|/|q|                    (:770-776)
+        //                    quad q += dq, rel = |dq|/max(1e-14,|q|), stop if rel<tol   (:1161-1169)
+        //                    ANN  q_p += dq, err = |dq|/(|q_p|+1e-14)                   (:1237-1244)
+        double base = 0.0;
+        if (lane < n) base = (a.mode == 1) ? a.wtu[(size_t)sys * n + lane] : a.q[(size_t)sys * n + lane];
+        const double qn = (lane < n) ? base + xout : 0.0;
+        if (lane < n) a.q[(size_t)sys * n + lane] = qn;
+        double nd, nq;
+        wave_sum2(xout * xout, qn * qn, nd, nq);
+        nd = sqrt(nd); nq = sqrt(nq);
+        const int k = a.iters[sys] + 1;
+        bool more;
+        double err;
+        if (a.mode == 1) { err = nd / nq; more = (err > a.tol) && (k < a.max_it); }
+        else if (a.mode == 2) { err = nd / fmax(1e-14, nq); more = !(err < a.tol) && (k < a.max_it); }
+        else { err = nd / (nq + 1e-14); more = (err > a.tol) && (k < a.max_it); }
+        if (lane == 0) {
+            a.iters[sys] = k;
+            a.active_io[sys] = more ? 1 : 0;
+            int f = 0;
+            if (!(err - err == 0.0)) f |= BG_FLAG_NONFINITE;
+            if (k >= a.max_it && ((a.mode == 2) ? !(err < a.tol) : true)) f |= BG_FLAG_HIT_CAP;
+            if (f) a.flags[sys] |= f;
+            if (more) atomicAdd(a.counter, 1);
+        }
+    }
 }
 
 template <typename F>
@@ -383,20 +449,23 @@ int bg_mass_rhs(int N, int B, const double* x, const double* un, const double* f
 int bg_rom_max_n(void) { return 512; }
 int bg_rom_max_r(void) { return 47; }
 
-int bg_rom_reduce(int N, int B, int r, int projection, const double* x, const double* W, long long w_stride,
-                  const double* U, const double* G, const double* hfs, const double* mu1, double dt, double E,
-                  int supg, const int32_t* active, double* Ar, double* br, double* wtu, void* stream)
+static int rom_reduce_impl(int N, int B, int r, int projection, const double* x, const double* W, long long w_stride,
+                           const double* U, const double* G, const double* hfs, const double* mu1, double dt, double E,
+                           int supg, const int32_t* active, double* Ar, double* br, double* wtu, const double* q_in,
+                           double* Uout, int lift_only, void* stream)
 {
     if (N < 2 || B < 0 || r < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
     if (projection != BG_PROJ_GALERKIN && projection != BG_PROJ_LSPG) return BG_ERR_PROJECTION;
     if (N > 512) return BG_ERR_UNSUPPORTED_N;
     if (r > 47) return BG_ERR_UNSUPPORTED_R;
     if (B == 0) return BG_OK;
-    if (!x || !W || !U || !G || !hfs || !mu1 || !Ar || !br) return BG_ERR_BAD_ARG;
+    if (!x || !W) return BG_ERR_BAD_ARG;
+    if (!lift_only && (!G || !hfs || !mu1 || !Ar || !br)) return BG_ERR_BAD_ARG;
+    if (q_in ? (!Uout || w_stride != 0) : !U) return BG_ERR_BAD_ARG;
     ReduceArgs a;
     a.x = x; a.W = W; a.w_stride = w_stride; a.U = U; a.G = G; a.hfs = hfs; a.mu1 = mu1; a.active = active;
     a.Ar = Ar; a.br = br; a.wtu = wtu; a.dt = dt; a.E = E; a.N = N; a.B = B; a.r = r; a.proj = projection;
-    a.supg = supg;
+    a.supg = supg; a.q_in = q_in; a.Uout = Uout; a.lift_only = lift_only;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -422,13 +491,54 @@ int bg_rom_reduce(int N, int B, int r, int projection, const double* x, const do
     return check_launch_rom();
 }
 
+int bg_rom_reduce(int N, int B, int r, int projection, const double* x, const double* W, long long w_stride,
+                  const double* U, const double* G, const double* hfs, const double* mu1, double dt, double E,
+                  int supg, const int32_t* active, double* Ar, double* br, double* wtu, void* stream)
+{
+    return rom_reduce_impl(N, B, r, projection, x, W, w_stride, U, G, hfs, mu1, dt, E, supg, active, Ar, br, wtu,
+                           nullptr, nullptr, 0, stream);
+}
+
+int bg_rom_reduce_lifted(int N, int B, int r, int projection, const double* x, const double* Phi, const double* q,
+                         double* U, const double* G, const double* hfs, const double* mu1, double dt, double E,
+                         int supg, const int32_t* active, double* Ar, double* br, double* wtu, void* stream)
+{
+    if (!q || !U) return BG_ERR_BAD_ARG;
+    return rom_reduce_impl(N, B, r, projection, x, Phi, 0, nullptr, G, hfs, mu1, dt, E, supg, active, Ar, br, wtu, q,
+                           U, 0, stream);
+}
+
+int bg_rom_lift(int N, int B, int r, const double* x, const double* Phi, const double* q, const int32_t* active,
+                double* U, void* stream)
+{
+    if (!q || !U) return BG_ERR_BAD_ARG;
+    return rom_reduce_impl(N, B, r, BG_PROJ_GALERKIN, x, Phi, 0, nullptr, nullptr, nullptr, nullptr, 1.0, 0.0, 0,
+                           active, nullptr, nullptr, nullptr, q, U, 1, stream);
+}
+
+int bg_lu_solve_update(int n, int B, const double* A, const double* b, int mode, const double* wtu, double* q,
+                       double* dq, double tol, int max_it, int32_t* active, int32_t* iters, int32_t* flags,
+                       int32_t* counter, int32_t* info, void* stream)
+{
+    if (n < 1 || B < 0 || mode < 1 || mode > 3) return BG_ERR_BAD_ARG;
+    if (B == 0) return BG_OK;
+    if (!A || !b || !q || !dq || !active || !iters || !flags || !counter || (mode == 1 && !wtu)) return BG_ERR_BAD_ARG;
+    LuArgs a{A, b, nullptr, dq, info, -1.0, n, B, mode, max_it, tol, wtu, q, active, iters, flags, counter};
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_lu(n, [&](auto nc) {
+        constexpr int NMAX = decltype(nc)::value;
+        hipLaunchKernelGGL((lu_solve_kernel<NMAX>), dim3((B + 3) / 4), dim3(256), 0, st, a);
+        return check_launch_rom();
+    });
+}
+
 int bg_lu_solve(int n, int B, const double* A, const double* b, double sign, const int32_t* active, double* x,
                 int32_t* info, void* stream)
 {
     if (n < 1 || B < 0) return BG_ERR_BAD_ARG;
     if (B == 0) return BG_OK;
     if (!A || !b || !x) return BG_ERR_BAD_ARG;
-    LuArgs a{A, b, active, x, info, sign, n, B};
+    LuArgs a{A, b, active, x, info, sign, n, B, 0, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     return dispatch_lu(n, [&](auto nc) {
         constexpr int NMAX = decltype(nc)::value;

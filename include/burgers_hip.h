@@ -142,6 +142,29 @@ int bg_rom_reduce(int N, int B, int r, int projection, const double *x, const do
 int bg_lu_solve(int n, int B, const double *A, const double *rhs, double sign, const int32_t *active,
                 double *x, int32_t *info, void *stream);
 
+/* bg_rom_reduce_lifted -- bg_rom_reduce for a shared basis Phi with the lift fused in:
+ *   u_k = Phi q is formed from the register-resident basis, stored to U[b] and used for the
+ *   assembly, so the state never round-trips through a GEMM.  reference: `U1 = Phi @ q` :773. */
+int bg_rom_reduce_lifted(int N, int B, int r, int projection, const double *x, const double *Phi,
+                         const double *q, double *U, const double *G, const double *hfs,
+                         const double *mu1, double dt, double E, int supg, const int32_t *active,
+                         double *Ar, double *br, double *wtu, void *stream);
+
+/* bg_rom_lift -- U[b] = Phi q[b] only (end of a time step). */
+int bg_rom_lift(int N, int B, int r, const double *x, const double *Phi, const double *q,
+                const int32_t *active, double *U, void *stream);
+
+/* bg_lu_solve_update -- bg_lu_solve(A, -rhs) fused with the reduced-coordinate update and the
+ * convergence bookkeeping of one batched iteration.  Samples with active[b] == 0 are skipped.
+ *   mode 1 (pod_prom_burgers :770-776):       q = wtu + dq;  err = |dq|/|q|;            go on while err > tol and k < max_it
+ *   mode 2 (pod_quadratic_manifold :1161-69): q += dq;       err = |dq|/max(1e-14,|q|); stop when err < tol (cap max_it)
+ *   mode 3 (pod_ann_prom :1237-1244):         q += dq;       err = |dq|/(|q|+1e-14);    go on while err > tol and k < max_it
+ *   iters[b] += 1; active[b] <- go on; flags[b] |= BG_FLAG_*; counter[0] += (#samples still
+ *   active), counter[1] += (#singular systems); the caller zeroes counter before the call. */
+int bg_lu_solve_update(int n, int B, const double *A, const double *rhs, int mode, const double *wtu,
+                       double *q, double *dq, double tol, int max_it, int32_t *active, int32_t *iters,
+                       int32_t *flags, int32_t *counter, int32_t *info, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
