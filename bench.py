@@ -51,7 +51,7 @@ def cpu_baseline(args, mu1, mu2):
     from oracle import burgers_ref_c as bc
     X = np.linspace(0.0, 100.0, args.n)
     threads = bc.max_threads()
-    nb = min(len(mu1), max(threads * 4, 16))
+    nb = min(len(mu1), max(threads * 8, 16))
     steps = min(args.time_steps, args.cpu_steps)
     bc.fom_run(X, np.ones(args.n), mu1[:2], mu2[:2], args.dt, 2)          # warm the thread pool
     t0 = time.perf_counter()
@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--n", type=int, default=1024, help="mesh nodes")
     ap.add_argument("--time-steps", type=int, default=500)
     ap.add_argument("--dt", type=float, default=0.025)
-    ap.add_argument("--cpu-steps", type=int, default=60, help="time steps of the CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=500, help="time steps of the CPU-baseline sample (8 samples per host thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -109,12 +109,19 @@ def main():
                   file=sys.stderr)
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     dist = None
+    backend = os.environ.get("BG_DIST_BACKEND", "nccl")     # "gloo" = CPU rehearsal of the multi-rank path
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from burgers_hip import fom, lib
     lib.load()
@@ -150,8 +157,8 @@ def main():
 
     steps_per_pass = int(out.iters.sum().item())           # sample-Newton-steps in one pass, this rank
     nonfinite = int((out.flags & lib.BG_FLAG_NONFINITE).ne(0).sum().item())
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(steps_per_pass)], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(steps_per_pass)], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
