@@ -37,16 +37,17 @@ def _as_dev(a, device, shape=None):
 
 
 def check_mesh(X):
+    """Validate the mesh and return it as host data (X is host data in the reference too)."""
     Xh = X.detach().cpu().numpy() if isinstance(X, torch.Tensor) else np.asarray(X, dtype=np.float64)
     if Xh.ndim != 1 or len(Xh) < 2:
         raise ValueError("X must be a 1-D array of at least 2 nodes")
-    if not _lib.mesh_is_uniform(Xh):
-        raise NotImplementedError("the HIP kernels cover uniform meshes (np.linspace) only")
+    if not np.all(np.diff(Xh) > 0):
+        raise ValueError("mesh nodes must be strictly increasing")
     return Xh
 
 
 def fom_run(X, u0, mu1, mu2, dt, nsteps, E=0.0, tol=1e-6, max_it=20, supg=True, device=None,
-            out=None, validate_mesh=True):
+            out=None, validate_mesh=True, options=None):
     """Run B samples through ``nsteps`` implicit-Euler steps on the current HIP stream.
 
     X (N,), u0 (N,) or (B, N), mu1/mu2 scalar or (B,).  Returns a :class:`FomResult` of
@@ -54,8 +55,8 @@ def fom_run(X, u0, mu1, mu2, dt, nsteps, E=0.0, tol=1e-6, max_it=20, supg=True, 
     """
     L = _lib.load()
     device = _lib.require_device(device)
-    if validate_mesh:
-        check_mesh(X)
+    if options is None:
+        options = _lib.mesh_options(check_mesh(X), supg) if validate_mesh else (_lib.BG_OPT_SUPG if supg else 0)
     Xd = _as_dev(X, device)
     N = Xd.numel()
     mu1d = _as_dev(mu1, device).reshape(-1)
@@ -77,7 +78,7 @@ def fom_run(X, u0, mu1, mu2, dt, nsteps, E=0.0, tol=1e-6, max_it=20, supg=True, 
         hist, iters, flags = out.hist, out.iters, out.flags
     with torch.cuda.device(device):
         rc = L.bg_fom_run(N, B, int(nsteps), _lib.ptr(Xd), _lib.ptr(u0d), _lib.ptr(mu1d), _lib.ptr(mu2d),
-                          float(dt), float(E), float(tol), int(max_it), 1 if supg else 0,
+                          float(dt), float(E), float(tol), int(max_it), int(options),
                           _lib.ptr(hist), _lib.ptr(iters), _lib.ptr(flags), _lib.stream_ptr(device))
     _lib.check(rc, "bg_fom_run")
     return FomResult(hist, iters, flags)
@@ -87,7 +88,7 @@ def fom_assemble(X, uk, un, mu1, mu2, dt, E=0.0, supg=True, device=None):
     """One Picard assembly: returns (lo, di, up, rhs), each (B, N); rhs = b - A(uk) uk."""
     L = _lib.load()
     device = _lib.require_device(device)
-    check_mesh(X)
+    options = _lib.mesh_options(check_mesh(X), supg)
     Xd = _as_dev(X, device)
     N = Xd.numel()
     ukd = _as_dev(uk, device).reshape(-1, N)
@@ -98,7 +99,7 @@ def fom_assemble(X, uk, un, mu1, mu2, dt, E=0.0, supg=True, device=None):
     outs = [torch.empty((B, N), dtype=torch.float64, device=device) for _ in range(4)]
     with torch.cuda.device(device):
         rc = L.bg_fom_assemble(N, B, _lib.ptr(Xd), _lib.ptr(ukd), _lib.ptr(und), _lib.ptr(mu1d),
-                               _lib.ptr(mu2d), float(dt), float(E), 1 if supg else 0,
+                               _lib.ptr(mu2d), float(dt), float(E), int(options),
                                *[_lib.ptr(o) for o in outs], _lib.stream_ptr(device))
     _lib.check(rc, "bg_fom_assemble")
     return tuple(outs)

@@ -27,6 +27,7 @@ BG_ERR_PROJECTION = -6
 BG_ERR_WORKSPACE = -7
 BG_PROJ_GALERKIN, BG_PROJ_LSPG = 0, 1
 BG_FLAG_HIT_CAP, BG_FLAG_NONFINITE = 1, 2
+BG_OPT_SUPG, BG_OPT_NONUNIFORM = 1, 2
 
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -49,9 +50,9 @@ _SIGNATURES = {
     "bg_rom_max_n": (ctypes.c_int, []),
     "bg_rom_max_r": (ctypes.c_int, []),
     "bg_forcing_setup": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_double,
-                                        c_double_p, c_double_p, ctypes.c_void_p]),
-    "bg_mass_rhs": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
-                                   ctypes.c_void_p]),
+                                        ctypes.c_int, c_double_p, c_double_p, ctypes.c_void_p]),
+    "bg_mass_rhs": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int,
+                                   c_double_p, ctypes.c_void_p]),
     "bg_rom_reduce": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
                                      c_double_p, ctypes.c_longlong, c_double_p, c_double_p, c_double_p,
                                      c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_int_p,
@@ -129,6 +130,11 @@ def ptr(t):
 
 def stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def mesh_options(X, supg=True):
+    """Option bits for the assembly-carrying entry points: SUPG on/off, uniform/non-uniform mesh."""
+    return (BG_OPT_SUPG if supg else 0) | (0 if mesh_is_uniform(X) else BG_OPT_NONUNIFORM)
 
 
 def mesh_is_uniform(X, rtol=1e-9):

@@ -41,6 +41,7 @@ class _Common:
     hfs: torch.Tensor
     dt: float
     E: float
+    mesh_opt: int = 0
 
     def stream(self):
         return _lib.stream_ptr(self.device)
@@ -49,7 +50,7 @@ class _Common:
 def _setup(X, u0, mu1, mu2, dt, E, device):
     L = _lib.load()
     device = _lib.require_device(device)
-    check_mesh(X)
+    mesh_opt = _lib.mesh_options(check_mesh(X), supg=False)
     Xd = _as_dev(X, device)
     N = Xd.numel()
     if N > L.bg_rom_max_n():
@@ -67,10 +68,10 @@ def _setup(X, u0, mu1, mu2, dt, E, device):
     with torch.cuda.device(device):
         for b0 in range(0, B, 32768):
             b1 = min(B, b0 + 32768)
-            _lib.check(L.bg_forcing_setup(N, b1 - b0, _lib.ptr(Xd), _lib.ptr(mu2d[b0:b1]), float(dt),
+            _lib.check(L.bg_forcing_setup(N, b1 - b0, _lib.ptr(Xd), _lib.ptr(mu2d[b0:b1]), float(dt), mesh_opt,
                                           _lib.ptr(fdt[b0:b1]), _lib.ptr(hfs[b0:b1]), _lib.stream_ptr(device)),
                        "bg_forcing_setup")
-    return _Common(L, device, Xd, N, B, mu1d, mu2d, u0d, fdt, hfs, float(dt), float(E))
+    return _Common(L, device, Xd, N, B, mu1d, mu2d, u0d, fdt, hfs, float(dt), float(E), mesh_opt)
 
 
 def _mass_rhs(c, Un, out):
@@ -78,7 +79,7 @@ def _mass_rhs(c, Un, out):
         for b0 in range(0, c.B, 32768):
             b1 = min(c.B, b0 + 32768)
             _lib.check(c.L.bg_mass_rhs(c.N, b1 - b0, _lib.ptr(c.X), _lib.ptr(Un[b0:b1]), _lib.ptr(c.fdt[b0:b1]),
-                                       _lib.ptr(out[b0:b1]), c.stream()), "bg_mass_rhs")
+                                       c.mesh_opt, _lib.ptr(out[b0:b1]), c.stream()), "bg_mass_rhs")
     return out
 
 
@@ -88,7 +89,7 @@ def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None):
     stride = 0 if W.dim() == 2 else c.N * r
     with torch.cuda.device(c.device):
         rc = c.L.bg_rom_reduce(c.N, c.B, r, proj, _lib.ptr(c.X), _lib.ptr(W), stride, _lib.ptr(U), _lib.ptr(G),
-                               _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, 1 if supg else 0,
+                               _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, (1 if supg else 0) | c.mesh_opt,
                                _lib.ptr(active) if active is not None else None, _lib.ptr(Ar), _lib.ptr(br),
                                _lib.ptr(wtu) if wtu is not None else None, c.stream())
     if rc == _lib.BG_ERR_UNSUPPORTED_R:
@@ -118,8 +119,8 @@ def rom_reduce_lifted(c, Phi, q, U, G, proj, supg, active, Ar, br, wtu):
     r = Phi.shape[1]
     with torch.cuda.device(c.device):
         rc = c.L.bg_rom_reduce_lifted(c.N, c.B, r, proj, _lib.ptr(c.X), _lib.ptr(Phi), _lib.ptr(q), _lib.ptr(U),
-                                      _lib.ptr(G), _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, 1 if supg else 0,
-                                      _lib.ptr(active) if active is not None else None, _lib.ptr(Ar), _lib.ptr(br),
+                                      _lib.ptr(G), _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E,
+                                      (1 if supg else 0) | c.mesh_opt, _lib.ptr(active) if active is not None else None, _lib.ptr(Ar), _lib.ptr(br),
                                       _lib.ptr(wtu) if wtu is not None else None, c.stream())
     if rc == _lib.BG_ERR_UNSUPPORTED_R:
         raise NotImplementedError(f"ROM kernels cover r <= {c.L.bg_rom_max_r()} (got {r})")

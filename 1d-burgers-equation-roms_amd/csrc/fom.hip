@@ -48,7 +48,7 @@ __device__ __forceinline__ void store_rows(double* __restrict__ dst, int N, int 
         if (full || row0 + j < N) dst[row0 + j] = u[j];
 }
 
-template <int R, bool FULL>
+template <int R, bool FULL, bool UNI = true>
 __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void fom_fused_kernel(FomArgs a)
 {
     const int lane = lane_id();
@@ -61,7 +61,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void fom_fused_kernel(FomArgs
     const double mu1 = a.mu1[s], mu2 = a.mu2[s];
 
     double hfs[R], fdt[R], u[R], g[R];
-    forcing_setup<R>(a.x, N, row0, mu2, c.h, a.dt, hfs, fdt);
+    ElemGeom<UNI ? 0 : R> gm;
+    if constexpr (UNI) {
+        forcing_setup<R>(a.x, N, row0, mu2, c.h, a.dt, hfs, fdt);
+    } else {
+        geom_setup<R>(a.x, N, row0, a.dt, a.E, gm);
+        forcing_setup_general<R>(a.x, N, row0, mu2, a.dt, hfs, fdt);
+    }
 
     double* hist = a.hist + (size_t)s * (size_t)(a.nsteps + 1) * (size_t)N;
     load_rows<R>(a.u0 + (size_t)s * N, N, row0, FULL, u);
@@ -69,12 +75,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void fom_fused_kernel(FomArgs
 
     int flags = 0;
     for (int step = 0; step < a.nsteps; ++step) {
-        mass_rhs<R, FULL>(c, N, row0, u, fdt, g);
+        if constexpr (UNI) mass_rhs<R, FULL>(c, N, row0, u, fdt, g);
+        else mass_rhs_general<R>(gm, N, row0, u, fdt, g);
         int k = 0;
         bool more;
         do {
             double lo[R], di[R], up[R], rhs[R];
-            assemble<R, FULL>(c, N, row0, mu1, u, g, hfs, lo, di, up, rhs);
+            if constexpr (UNI) assemble<R, FULL>(c, N, row0, mu1, u, g, hfs, lo, di, up, rhs);
+            else assemble_general<R>(gm, a.dt, c.kap, N, row0, mu1, u, g, hfs, lo, di, up, rhs);
             tridiag_solve<R>(lo, di, up, rhs);
             double nd = 0.0, nu = 0.0;
 #pragma unroll
@@ -105,7 +113,7 @@ struct AsmArgs {
     int N, B, supg;
 };
 
-template <int R, bool FULL>
+template <int R, bool FULL, bool UNI = true>
 __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void fom_assemble_kernel(AsmArgs a)
 {
     const int lane = lane_id();
@@ -115,11 +123,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void fom_assemble_kernel(AsmA
     const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
     const MeshConst c = make_mesh_const(h, a.dt, a.E, a.supg);
     double hfs[R], fdt[R], u[R], un[R], g[R], lo[R], di[R], up[R], rhs[R];
-    forcing_setup<R>(a.x, N, row0, a.mu2[s], c.h, a.dt, hfs, fdt);
     load_rows<R>(a.un + (size_t)s * N, N, row0, FULL, un);
     load_rows<R>(a.uk + (size_t)s * N, N, row0, FULL, u);
-    mass_rhs<R, FULL>(c, N, row0, un, fdt, g);
-    assemble<R, FULL>(c, N, row0, a.mu1[s], u, g, hfs, lo, di, up, rhs);
+    if constexpr (UNI) {
+        forcing_setup<R>(a.x, N, row0, a.mu2[s], c.h, a.dt, hfs, fdt);
+        mass_rhs<R, FULL>(c, N, row0, un, fdt, g);
+        assemble<R, FULL>(c, N, row0, a.mu1[s], u, g, hfs, lo, di, up, rhs);
+    } else {
+        ElemGeom<R> gm;
+        geom_setup<R>(a.x, N, row0, a.dt, a.E, gm);
+        forcing_setup_general<R>(a.x, N, row0, a.mu2[s], a.dt, hfs, fdt);
+        mass_rhs_general<R>(gm, N, row0, un, fdt, g);
+        assemble_general<R>(gm, a.dt, c.kap, N, row0, a.mu1[s], u, g, hfs, lo, di, up, rhs);
+    }
     store_rows<R>(a.lo + (size_t)s * N, N, row0, FULL, lo);
     store_rows<R>(a.di + (size_t)s * N, N, row0, FULL, di);
     store_rows<R>(a.up + (size_t)s * N, N, row0, FULL, up);
@@ -248,12 +264,15 @@ int bg_fom_run(int N, int B, int nsteps, const double* x, const double* u0, cons
     FomArgs a;
     a.x = x; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
     a.dt = dt; a.E = E; a.tol2 = tol * tol;
-    a.N = N; a.B = B; a.nsteps = nsteps; a.max_it = max_it; a.supg = supg;
+    a.N = N; a.B = B; a.nsteps = nsteps; a.max_it = max_it; a.supg = supg & BG_OPT_SUPG;
+    const bool nonuniform = (supg & BG_OPT_NONUNIFORM) != 0;
     const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
     return dispatch_r(N, [&](auto rc) {
         constexpr int R = decltype(rc)::value;
-        if (N == 64 * R)
+        if (nonuniform)
+            hipLaunchKernelGGL((fom_fused_kernel<R, false, false>), grid, block, 0, st, a);
+        else if (N == 64 * R)
             hipLaunchKernelGGL((fom_fused_kernel<R, true>), grid, block, 0, st, a);
         else
             hipLaunchKernelGGL((fom_fused_kernel<R, false>), grid, block, 0, st, a);
@@ -270,12 +289,15 @@ int bg_fom_assemble(int N, int B, const double* x, const double* uk, const doubl
     if (!x || !uk || !un || !mu1 || !mu2 || !lo || !di || !up || !rhs) return BG_ERR_BAD_ARG;
     AsmArgs a;
     a.x = x; a.uk = uk; a.un = un; a.mu1 = mu1; a.mu2 = mu2; a.lo = lo; a.di = di; a.up = up; a.rhs = rhs;
-    a.dt = dt; a.E = E; a.N = N; a.B = B; a.supg = supg;
+    a.dt = dt; a.E = E; a.N = N; a.B = B; a.supg = supg & BG_OPT_SUPG;
+    const bool nonuniform = (supg & BG_OPT_NONUNIFORM) != 0;
     const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
     return dispatch_r(N, [&](auto rc) {
         constexpr int R = decltype(rc)::value;
-        if (N == 64 * R)
+        if (nonuniform)
+            hipLaunchKernelGGL((fom_assemble_kernel<R, false, false>), grid, block, 0, st, a);
+        else if (N == 64 * R)
             hipLaunchKernelGGL((fom_assemble_kernel<R, true>), grid, block, 0, st, a);
         else
             hipLaunchKernelGGL((fom_assemble_kernel<R, false>), grid, block, 0, st, a);

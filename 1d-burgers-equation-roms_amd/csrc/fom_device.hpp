@@ -163,6 +163,137 @@ __device__ __forceinline__ void assemble(const MeshConst& c, int N, int row0, do
     }
 }
 
+// ------------------------------------------------------------------------------------
+// General (non-uniform) mesh variants.  Element e = (i, i+1) has length h_e = x[i+1]-x[i];
+// the lane keeps h_e/6 and dt*E/h_e of its R right-hand elements plus the one left of its
+// first row (index 0).  Same closed forms as above with per-element constants
+// (SURVEY.md Appendix A); rows >= N are identity rows.  Slower than the uniform path
+// (more live registers); used only when the host reports a non-uniform mesh.
+// ------------------------------------------------------------------------------------
+template <int R>
+struct ElemGeom {
+    double h6[R + 1];   // h_e / 6        (index j+1: element right of local row j; index 0: left of row 0)
+    double eh[R + 1];   // dt * E / h_e
+};
+
+template <int R>
+__device__ __forceinline__ void geom_setup(const double* __restrict__ x, int N, int row0, double dt, double E,
+                                           ElemGeom<R>& gm)
+{
+#pragma unroll
+    for (int j = 0; j <= R; ++j) {
+        const int e = row0 + j - 1;                       // element (e, e+1)
+        double h = 1.0;
+        if (e >= 0 && e < N - 1) h = x[e + 1] - x[e];
+        gm.h6[j] = (e >= 0 && e < N - 1) ? h / 6.0 : 0.0;
+        gm.eh[j] = (e >= 0 && e < N - 1) ? dt * E / h : 0.0;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void forcing_setup_general(const double* __restrict__ x, int N, int row0, double mu2,
+                                                      double dt, double (&hfs)[R], double (&fdt)[R])
+{
+    double frPrev = 0.0;
+#pragma unroll
+    for (int j = -1; j < R; ++j) {
+        const int e = row0 + j;
+        double fl = 0.0, fr = 0.0, hf = 0.0;
+        if (e >= 0 && e < N - 1) {
+            const double xl = x[e], xr = x[e + 1], h = xr - xl;
+            const double f1 = 0.02 * exp(mu2 * (GP_A * xl + GP_B * xr));
+            const double f2 = 0.02 * exp(mu2 * (GP_B * xl + GP_A * xr));
+            fl = (f1 * GP_A + f2 * GP_B) * (0.5 * h);
+            fr = (f1 * GP_B + f2 * GP_A) * (0.5 * h);
+            hf = h * (f1 + f2);
+        }
+        if (j >= 0) {
+            hfs[j] = hf;
+            fdt[j] = (e < N) ? dt * (frPrev + fl) : 0.0;
+        }
+        frPrev = fr;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void mass_rhs_general(const ElemGeom<R>& gm, int N, int row0, const double (&u)[R],
+                                                 const double (&fdt)[R], double (&g)[R])
+{
+    const double uL = from_lane_below(u[R - 1]);
+    const double uR = from_lane_above(u[0]);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const double um = (j == 0) ? uL : u[j - 1];
+        const double up = (j == R - 1) ? uR : u[j + 1];
+        const int i = row0 + j;
+        // (M u)_i = h_{i-1}/6 (u_{i-1} + 2 u_i) + h_i/6 (2 u_i + u_{i+1}); h6 is 0 outside the mesh
+        double v = gm.h6[j] * __builtin_fma(2.0, u[j], um);
+        v = __builtin_fma(gm.h6[j + 1], __builtin_fma(2.0, u[j], up), v);
+        g[j] = (i >= N) ? 0.0 : v + fdt[j];
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void assemble_general(const ElemGeom<R>& gm, double dt, double kap, int N, int row0,
+                                                 double mu1, const double (&u)[R], const double (&g)[R],
+                                                 const double (&hfs)[R], double (&lo)[R], double (&di)[R],
+                                                 double (&up)[R], double (&rhs)[R])
+{
+    const int lane = lane_id();
+    const double dt6 = dt / 6.0;
+    const double uL = from_lane_below(u[R - 1]);
+    const double uR = from_lane_above(u[0]);
+    double se[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const double ur = (j == R - 1) ? uR : u[j + 1];
+        const double w = u[j] + ur;
+        const double dif = ur - u[j];
+        const double aoff = gm.h6[j + 1] - gm.eh[j + 1];
+        up[j] = __builtin_fma(dt6, w + u[j], aoff);
+        if (j + 1 < R) lo[j + 1] = __builtin_fma(-dt6, w + ur, aoff);
+        const double mx = fmax(fabs(w), 2.0e-10);
+        const double t = __builtin_fma(w, dif, -hfs[j]);
+        se[j] = t * BG_RCP(mx);
+    }
+    lo[0] = __builtin_fma(-dt6, __builtin_fma(2.0, u[0], uL), gm.h6[0] - gm.eh[0]);
+    const double seL = from_lane_below(se[R - 1]);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const double um = (j == 0) ? uL : u[j - 1];
+        const double ur = (j == R - 1) ? uR : u[j + 1];
+        const double sm = (j == 0) ? seL : se[j - 1];
+        const int i = row0 + j;
+        const double ddl = __builtin_fma(2.0, gm.h6[j], gm.eh[j]);          // h/3 + dt E/h of the left element
+        const double ddr = __builtin_fma(2.0, gm.h6[j + 1], gm.eh[j + 1]);  // ... of the right element
+        double d = __builtin_fma(dt6, um - ur, ddl + ddr);
+        double b = __builtin_fma(-kap, sm, g[j]);
+        double bb = __builtin_fma(kap, se[j], b);
+        double l = lo[j], p = up[j];
+        const bool is_last = (i == N - 1);
+        const double dl = __builtin_fma(dt6, __builtin_fma(2.0, u[j], um), ddl);
+        d = is_last ? dl : d;
+        p = is_last ? 0.0 : p;
+        bb = is_last ? b : bb;
+        const bool pad = i >= N;
+        d = pad ? 1.0 : d;
+        p = pad ? 0.0 : p;
+        l = pad ? 0.0 : l;
+        bb = pad ? 0.0 : bb;
+        if (j == 0) {
+            const bool first = lane == 0;
+            d = first ? 1.0 : d;
+            p = first ? 0.0 : p;
+            l = first ? 0.0 : l;
+            bb = first ? mu1 : bb;
+        }
+        double r = __builtin_fma(-l, um, bb);
+        r = __builtin_fma(-d, u[j], r);
+        r = __builtin_fma(-p, ur, r);
+        lo[j] = l; di[j] = d; up[j] = p; rhs[j] = r;
+    }
+}
+
 // One PCR step on normalised equations A x[j-s] + x[j] + C x[j+s] = D; neighbours come from
 // DPP moves (CTRL_DN: from lower lanes, CTRL_UP: from higher lanes, applied REPS times, zero
 // filled out of range, which is the identity equation).  LAST skips the A/C update.

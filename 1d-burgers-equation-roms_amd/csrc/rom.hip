@@ -33,43 +33,52 @@ int check_launch_rom()
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void forcing_setup_kernel(const double* __restrict__ x,
                                                             const double* __restrict__ mu2, int N, int B,
-                                                            double dt, double* __restrict__ fdt,
+                                                            double dt, int nonuniform, double* __restrict__ fdt,
                                                             double* __restrict__ hfs)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N || b >= B) return;
-    const double h = (x[N - 1] - x[0]) / (double)(N - 1);
+    const double hu = (x[N - 1] - x[0]) / (double)(N - 1);
     const double m = mu2[b];
-    double frPrev = 0.0, fl = 0.0, fs = 0.0;
+    double frPrev = 0.0, fl = 0.0, hf = 0.0;
     if (i > 0) {
         const double xl = x[i - 1], xr = x[i];
+        const double h = nonuniform ? xr - xl : hu;
         const double f1 = 0.02 * exp(m * (GP_A * xl + GP_B * xr));
         const double f2 = 0.02 * exp(m * (GP_B * xl + GP_A * xr));
         frPrev = (f1 * GP_B + f2 * GP_A) * (0.5 * h);
     }
     if (i < N - 1) {
         const double xl = x[i], xr = x[i + 1];
+        const double h = nonuniform ? xr - xl : hu;
         const double f1 = 0.02 * exp(m * (GP_A * xl + GP_B * xr));
         const double f2 = 0.02 * exp(m * (GP_B * xl + GP_A * xr));
         fl = (f1 * GP_A + f2 * GP_B) * (0.5 * h);
-        fs = f1 + f2;
+        hf = h * (f1 + f2);
     }
     fdt[(size_t)b * N + i] = dt * (frPrev + fl);
-    hfs[(size_t)b * N + i] = h * fs;
+    hfs[(size_t)b * N + i] = hf;
 }
 
 // g = M u^n + dt F      reference: `M @ U[:, n] + At*F` of :683
 __global__ __launch_bounds__(256) void mass_rhs_kernel(const double* __restrict__ x,
                                                        const double* __restrict__ un,
                                                        const double* __restrict__ fdt, int N, int B,
-                                                       double* __restrict__ g)
+                                                       int nonuniform, double* __restrict__ g)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N || b >= B) return;
-    const double h6 = (x[N - 1] - x[0]) / (double)(N - 1) / 6.0;
     const double* u = un + (size_t)b * N;
+    if (nonuniform) {
+        double v = 0.0;
+        if (i > 0) v = (x[i] - x[i - 1]) / 6.0 * __builtin_fma(2.0, u[i], u[i - 1]);
+        if (i < N - 1) v = __builtin_fma((x[i + 1] - x[i]) / 6.0, __builtin_fma(2.0, u[i], u[i + 1]), v);
+        g[(size_t)b * N + i] = v + fdt[(size_t)b * N + i];
+        return;
+    }
+    const double h6 = (x[N - 1] - x[0]) / (double)(N - 1) / 6.0;
     double acc;
     if (i == 0)
         acc = __builtin_fma(2.0, u[0], u[1]);
@@ -104,7 +113,7 @@ struct ReduceArgs {
     const double* q_in;      // [B][r] or null: if given, u = W q is formed here and stored to Uout
     double* Uout;            // [B][N] (only with q_in)
     double dt, E;
-    int N, B, r, proj, supg, lift_only;
+    int N, B, r, proj, supg, lift_only, nonuniform;
 };
 
 template <int S, int NT>
@@ -182,24 +191,33 @@ __global__ __launch_bounds__(256, 1) void rom_reduce_kernel(ReduceArgs a)
             if (i < N) {
                 const double um = s_u[i], u0 = s_u[i + 1], ur = s_u[i + 2];
                 const double gi = a.G[(size_t)smp * N + i];
+                double aoffL = mc.aoff, aoffR = mc.aoff, ddL = mc.dd1, ddR = mc.dd1;
+                if (a.nonuniform && i > 0) {                          // per-element lengths
+                    const double hl = a.x[i] - a.x[i - 1];
+                    aoffL = hl / 6.0 - a.dt * a.E / hl; ddL = hl / 3.0 + a.dt * a.E / hl;
+                    if (i < N - 1) {
+                        const double hr = a.x[i + 1] - a.x[i];
+                        aoffR = hr / 6.0 - a.dt * a.E / hr; ddR = hr / 3.0 + a.dt * a.E / hr;
+                    }
+                }
                 if (i == 0) {
                     rhs = mu1 - u0;                                   // Dirichlet row
                 } else {
                     // left element (i-1, i)
                     const double wl = um + u0;
-                    lo = __builtin_fma(-mc.dt6, wl + u0, mc.aoff);
+                    lo = __builtin_fma(-mc.dt6, wl + u0, aoffL);
                     const double tl = __builtin_fma(wl, u0 - um, -a.hfs[(size_t)smp * N + i - 1]);
                     const double sl = tl * rcp(fmax(fabs(wl), 2.0e-10));
                     double b = __builtin_fma(-mc.kap, sl, gi);
                     if (i < N - 1) {
                         const double wr = u0 + ur;
-                        up = __builtin_fma(mc.dt6, wr + u0, mc.aoff);
-                        di = __builtin_fma(mc.dt6, um - ur, mc.dd2);
+                        up = __builtin_fma(mc.dt6, wr + u0, aoffR);
+                        di = __builtin_fma(mc.dt6, um - ur, ddL + ddR);
                         const double tr = __builtin_fma(wr, ur - u0, -a.hfs[(size_t)smp * N + i]);
                         const double sr = tr * rcp(fmax(fabs(wr), 2.0e-10));
                         b = __builtin_fma(mc.kap, sr, b);
                     } else {
-                        di = __builtin_fma(mc.dt6, wl + u0, mc.dd1);
+                        di = __builtin_fma(mc.dt6, wl + u0, ddL);
                     }
                     rhs = __builtin_fma(-lo, um, b);
                     rhs = __builtin_fma(-di, u0, rhs);
@@ -425,24 +443,25 @@ int dispatch_lu(int n, F&& f)
 
 extern "C" {
 
-int bg_forcing_setup(int N, int B, const double* x, const double* mu2, double dt, double* fdt, double* hfs,
-                     void* stream)
+int bg_forcing_setup(int N, int B, const double* x, const double* mu2, double dt, int options, double* fdt,
+                     double* hfs, void* stream)
 {
     if (N < 2 || B < 0) return BG_ERR_BAD_ARG;
     if (B == 0) return BG_OK;
     if (!x || !mu2 || !fdt || !hfs || B > 65535) return BG_ERR_BAD_ARG;
     hipLaunchKernelGGL(forcing_setup_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, mu2, N,
-                       B, dt, fdt, hfs);
+                       B, dt, (options & BG_OPT_NONUNIFORM) ? 1 : 0, fdt, hfs);
     return check_launch_rom();
 }
 
-int bg_mass_rhs(int N, int B, const double* x, const double* un, const double* fdt, double* g, void* stream)
+int bg_mass_rhs(int N, int B, const double* x, const double* un, const double* fdt, int options, double* g,
+                void* stream)
 {
     if (N < 2 || B < 0) return BG_ERR_BAD_ARG;
     if (B == 0) return BG_OK;
     if (!x || !un || !fdt || !g || B > 65535) return BG_ERR_BAD_ARG;
     hipLaunchKernelGGL(mass_rhs_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, un, fdt, N, B,
-                       g);
+                       (options & BG_OPT_NONUNIFORM) ? 1 : 0, g);
     return check_launch_rom();
 }
 
@@ -465,7 +484,8 @@ static int rom_reduce_impl(int N, int B, int r, int projection, const double* x,
     ReduceArgs a;
     a.x = x; a.W = W; a.w_stride = w_stride; a.U = U; a.G = G; a.hfs = hfs; a.mu1 = mu1; a.active = active;
     a.Ar = Ar; a.br = br; a.wtu = wtu; a.dt = dt; a.E = E; a.N = N; a.B = B; a.r = r; a.proj = projection;
-    a.supg = supg; a.q_in = q_in; a.Uout = Uout; a.lift_only = lift_only;
+    a.supg = supg & BG_OPT_SUPG; a.nonuniform = (supg & BG_OPT_NONUNIFORM) ? 1 : 0;
+    a.q_in = q_in; a.Uout = Uout; a.lift_only = lift_only;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)

@@ -42,6 +42,10 @@ enum {
 
 enum { BG_PROJ_GALERKIN = 0, BG_PROJ_LSPG = 1 };
 
+/* option bits of the `supg` / `options` argument of the assembly-carrying entry points */
+enum { BG_OPT_SUPG = 1,        /* include the SUPG vector (fom_burgers, pod_prom_burgers, pod_ann_prom) */
+       BG_OPT_NONUNIFORM = 2   /* x is not a linspace: use the per-element-length kernels          */ };
+
 /* per-sample status bits written to `flags` */
 enum { BG_FLAG_HIT_CAP = 1, BG_FLAG_NONFINITE = 2 };
 
@@ -59,15 +63,15 @@ int bg_fom_max_n(void);
  *   compute_convection_matrix :389-425, compute_forcing_vector :427-461,
  *   compute_supg_term :500-581 and scipy spsolve :692 fused into one kernel.
  *
- *   x      [N]               mesh nodes; must be uniform (linspace) -> else BG_ERR_NONUNIFORM
- *                            is reported by bg_mesh_is_uniform on the host side
+ *   x      [N]               mesh nodes, strictly increasing; pass BG_OPT_NONUNIFORM in `supg` when
+ *                            they are not a linspace (the host knows: X is host data in the reference)
  *   u0     [B][N]            initial state per sample
  *   mu1,mu2[B]               Dirichlet value u(0,t) and source exponent per sample
  *   hist   [B][nsteps+1][N]  hist[b][0] = u0[b]; hist[b][t+1] = state after step t
  *   iters  [B][nsteps]       Picard iterations taken per step (the reference's k)
  *   flags  [B]               BG_FLAG_* bits
  *   tol, max_it              the reference hard-codes 1e-6 and 20 (:663)
- *   supg                     1 = include the SUPG vector (fom_burgers), 0 = omit
+ *   supg                     option bits: BG_OPT_SUPG (fom_burgers has it) | BG_OPT_NONUNIFORM
  * --------------------------------------------------------------------------------- */
 int bg_fom_run(int N, int B, int nsteps, const double *x, const double *u0, const double *mu1,
                const double *mu2, double dt, double E, double tol, int max_it, int supg,
@@ -112,13 +116,13 @@ int bg_rom_max_r(void);
  *   reference: compute_forcing_vector FEM/fem_burgers.py:427-461 (the reference recomputes
  *   it every iteration, :673) and the f_gp terms of compute_supg_term :556-558.
  *   fdt[b][i] = dt * F_i(mu2_b);  hfs[b][e] = h_e * (f(gp1) + f(gp2)), hfs[b][N-1] = 0. */
-int bg_forcing_setup(int N, int B, const double *x, const double *mu2, double dt, double *fdt,
-                     double *hfs, void *stream);
+int bg_forcing_setup(int N, int B, const double *x, const double *mu2, double dt, int options,
+                     double *fdt, double *hfs, void *stream);
 
 /* bg_mass_rhs -- g[b] = M u^n[b] + dt F[b], once per time step
  *   reference: `M @ U[:, n] + At*F` at FEM/fem_burgers.py:683 / :746 / :1141 / :1214. */
-int bg_mass_rhs(int N, int B, const double *x, const double *un, const double *fdt, double *g,
-                void *stream);
+int bg_mass_rhs(int N, int B, const double *x, const double *un, const double *fdt, int options,
+                double *g, void *stream);
 
 /* bg_rom_reduce -- fused assembly + projection of one iteration, fp64 MFMA
  *   reference: FEM/fem_burgers.py:730-762 (pod_prom_burgers), :1134-1156

@@ -147,9 +147,9 @@ def test_edge_cases(hip):
     # N outside the single-wave range and non-uniform meshes are refused, not mis-computed
     with pytest.raises(lib.BurgersHipError):
         fom.fom_run(np.linspace(0, 100, 1500), np.ones(1500), 4.5, 0.02, 0.05, 1)
-    Xn = X.copy(); Xn[7] += 0.05
-    with pytest.raises(NotImplementedError):
-        fom.fom_run(Xn, np.ones(256), 4.5, 0.02, 0.05, 1)
+    Xbad = X.copy(); Xbad[7] = Xbad[9]
+    with pytest.raises(ValueError):                     # nodes must be strictly increasing
+        fom.fom_run(Xbad, np.ones(256), 4.5, 0.02, 0.05, 1)
     # divergence (reference finding: N=1024 at dt=0.05 hits the cap every step) is flagged, not hidden
     X2, _ = mesh(1024)
     r = fom.fom_run(X2, np.ones(1024), 5.5, 0.03, 0.05, 12)
@@ -175,3 +175,32 @@ def test_facade_drop_in(hip):
     assert np.array_equal(u0, np.ones_like(X))                     # inputs are never mutated
     Ub = fem.fom_burgers(0.05, 10, u0, np.array([4.75, 5.0]), 0.0, np.array([0.02, 0.025]))
     assert Ub.shape == (2, 256, 11) and rel_l2(Ub[0], g["U"][:, :11]) < TOL
+
+
+def test_nonuniform_mesh_golden_and_oracle(hip):
+    """The reference accepts any mesh; the non-uniform kernels are pinned by a live-reference run
+    on a perturbed 96-node mesh with E != 0 and by the oracle on larger perturbed meshes."""
+    from burgers_hip import fom
+    g = load_golden("fom_general.npz")
+    h, it, fl = _run(hip, g["X"], g["u0"], float(g["mu1"]), float(g["mu2"]), float(g["At"]), int(g["nT"]),
+                     E=float(g["E"]))
+    assert rel_l2(h[0].T, g["U"]) < TOL and np.array_equal(it[0], g["iters"])
+    # assembly pieces on the same mesh against the dumped reference matrices
+    X, u, mu2 = g["X"], g["u"], float(g["mu2"])
+    lo, di, up, rhs = [t.cpu().numpy()[0] for t in fom.fom_assemble(X, u, u, 3.3, mu2, 0.02, E=0.05)]
+    A_ref = g["M"] + 0.02 * g["C"] + 0.02 * 0.05 * g["K"]
+    A_ref[0, :] = 0; A_ref[0, 0] = 1
+    A = br.tridiag_dense(lo, di, up)
+    assert np.abs(A - A_ref).max() < 1e-13
+    b_ref = g["M"] @ u + 0.02 * g["F"] - 0.02 * g["S"]; b_ref[0] = 3.3
+    assert np.abs(rhs - (b_ref - A_ref @ u)).max() < 1e-12
+    rng = np.random.default_rng(9)
+    for N in (512, 1024, 300):
+        X = np.linspace(0, 100, N) + rng.uniform(-0.3, 0.3, N) * (100 / (N - 1))
+        X[0], X[-1] = 0.0, 100.0
+        B = 5
+        mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+        dt = 0.05 * 512 / N
+        h, it, fl = _run(hip, X, np.ones(N), mu1, mu2, dt, 15, E=0.002)
+        ho, ito = bc.fom_run(X, np.ones(N), mu1, mu2, dt, 15, E=0.002)
+        assert rel_l2(h, ho) < TOL and np.array_equal(it, ito), N

@@ -205,3 +205,43 @@ def test_facade_rom_methods(hip):
     a = load_golden("ann_n5.npz")
     U = fem.pod_ann_prom(0.05, 4, np.ones(512), 4.56, 0.0, 0.019, a["U_p"], a["U_s"], _ann_model(a))
     assert U.shape == (512, 5) and rel_l2(U, a["U"]) < 5e-6
+
+
+def test_rom_nonuniform_mesh_vs_oracle(hip):
+    """ROM path on a perturbed mesh (per-element lengths in the fused assembly): the reduce
+    kernel against the oracle's projection, then full POD runs."""
+    from burgers_hip import rom
+    g = load_golden("committed_pod_r40.npz")
+    rng = np.random.default_rng(21)
+    N = 512
+    X = np.linspace(0, 100, N) + rng.uniform(-0.3, 0.3, N) * (100 / (N - 1))
+    X[0], X[-1] = 0.0, 100.0
+    Phi = g["Phi"]
+    B, dt, E = 3, 0.05, 0.003
+    mu1 = np.array([4.6, 5.2, 4.9]); mu2 = np.array([0.02, 0.027, 0.016])
+    U = 1.0 + 4.0 * rng.random((B, N)); Un = 1.0 + 4.0 * rng.random((B, N))
+    c = rom._setup(X, Un, mu1, mu2, dt, E, None)
+    assert c.mesh_opt == 2
+    G = torch.empty((B, N), dtype=torch.float64, device="cuda")
+    rom._mass_rhs(c, _dev(Un), G)
+    M3, K3 = br.mass_tridiag(X), br.diffusion_tridiag(X)
+    for pname, proj in (("galerkin", 0), ("lspg", 1)):
+        Ar = torch.zeros((B, 40, 40), dtype=torch.float64, device="cuda")
+        brr = torch.zeros((B, 40), dtype=torch.float64, device="cuda")
+        rom.rom_reduce(c, _dev(Phi), _dev(U), G, proj, True, None, Ar, brr, None)
+        torch.cuda.synchronize()
+        for b in range(B):
+            lo, di, up = br.system_tridiag(M3, K3, br.convection_tridiag(X, U[b]), dt, E)
+            bb = br.tridiag_matvec(*M3, Un[b]) + dt * br.forcing_vector(X, mu2[b]) - dt * br.supg_term(X, U[b], mu2[b])
+            bb[0] = mu1[b]
+            R = br.tridiag_matvec(lo, di, up, U[b]) - bb
+            Ar_ref, br_ref = br._reduce(lo, di, up, R, Phi, pname)
+            assert rel_l2(Ar[b].cpu().numpy(), Ar_ref) < 1e-13
+            assert rel_l2(brr[b].cpu().numpy(), br_ref) < 1e-12
+    for proj in ("Galerkin", "LSPG"):
+        res = rom.pod_prom_run(X, np.ones(N), mu1, mu2, dt, 8, Phi, projection=proj, E=E)
+        torch.cuda.synchronize()
+        for b in range(B):
+            Uo, ito = br.pod_prom_burgers(X, dt, 8, np.ones(N), mu1[b], E, mu2[b], Phi, projection=proj, return_iters=True)
+            assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < TOL
+            assert np.array_equal(res.iters[b].cpu().numpy(), ito)
