@@ -289,6 +289,85 @@ def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0,
 
 
 # ----------------------------------------------------------------------- POD-ANN
+def _mlp_layers(model):
+    """Recognise a plain MLP: nn.Sequential of Linear / ELU|ReLU|Tanh, or the reference's POD_ANN
+    class (fc1..fcK + self.elu, POD-ANN/pod_ann.py:38-56).  Returns [(Linear, act-or-None)] or None."""
+    import torch.nn as nn
+    acts = (nn.ELU, nn.ReLU, nn.Tanh)
+    if isinstance(model, nn.Sequential):
+        mods = list(model)
+        out, i = [], 0
+        while i < len(mods):
+            if not isinstance(mods[i], nn.Linear):
+                return None
+            act = None
+            if i + 1 < len(mods) and isinstance(mods[i + 1], acts):
+                act = mods[i + 1]; i += 1
+            out.append((mods[i - (1 if act is not None else 0)], act))
+            i += 1
+        return out if out else None
+    fcs = []
+    while isinstance(getattr(model, f"fc{len(fcs) + 1}", None), nn.Linear):
+        fcs.append(getattr(model, f"fc{len(fcs) + 1}"))
+    elu = getattr(model, "elu", None)
+    if len(fcs) >= 2 and isinstance(elu, nn.ELU):
+        return [(fc, elu if i < len(fcs) - 1 else None) for i, fc in enumerate(fcs)]
+    return None
+
+
+def _mlp_forward_jacobian(layers, x, want_jac=True):
+    """Forward pass and forward-mode input-Jacobian of a recognised MLP as batched GEMMs."""
+    import torch.nn as nn
+    J = None
+    for lin, act in layers:
+        z = torch.addmm(lin.bias, x, lin.weight.t()) if lin.bias is not None else x @ lin.weight.t()
+        if want_jac:
+            J = lin.weight.unsqueeze(0).expand(x.shape[0], -1, -1) if J is None else torch.matmul(lin.weight, J)
+        if act is None:
+            x = z
+            continue
+        if isinstance(act, nn.ELU):
+            x = torch.nn.functional.elu(z, alpha=act.alpha)
+            d = torch.where(z > 0, torch.ones_like(z), act.alpha * torch.exp(z))
+        elif isinstance(act, nn.ReLU):
+            x = torch.relu(z); d = (z > 0).to(z.dtype)
+        else:
+            x = torch.tanh(z); d = 1.0 - x * x
+        if want_jac:
+            J = d.unsqueeze(-1) * J
+    return x, J
+
+
+class AnnEvaluator:
+    """model(q) and d model / d q for a batch, in the model's dtype.  A recognised MLP runs as a
+    few batched GEMMs (checked against the module itself on a probe); anything else falls back
+    to torch.func (vmap of jacfwd), the batched stand-in for the reference's per-sample
+    torch.autograd.functional.jacobian (:1254-1275)."""
+
+    def __init__(self, model, n, dtype):
+        self.model, self.dtype = model, dtype
+        self.layers = _mlp_layers(model)
+        if self.layers is not None:
+            dev = next(model.parameters()).device
+            probe = torch.linspace(-1.0, 1.0, 4 * n, device=dev, dtype=dtype).reshape(4, n)
+            with torch.no_grad():
+                ok = torch.allclose(model(probe), _mlp_forward_jacobian(self.layers, probe, False)[0],
+                                    rtol=1e-3 if dtype != torch.float32 else 1e-5, atol=1e-5)
+            if not ok:
+                self.layers = None
+
+    def forward(self, q):
+        with torch.no_grad():
+            return self.model(q.to(self.dtype)).to(torch.float64)
+
+    def jacobian(self, q):
+        with torch.no_grad():
+            x = q.to(self.dtype)
+            if self.layers is not None:
+                return _mlp_forward_jacobian(self.layers, x)[1].to(torch.float64)
+            return ann_jacobian(self.model, x).to(torch.float64)
+
+
 def ann_jacobian(model, q32):
     """Batched input-Jacobian (B, nbar, n) of ``model`` in fp32; forward mode, since n << nbar.
     Stand-in for the per-sample torch.autograd.functional.jacobian of :1254-1275."""
@@ -308,7 +387,8 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
     Up, Us = _as_dev(U_p, c.device), _as_dev(U_s, c.device)
     n = Up.shape[1]
     UpT, UsT = Up.t().contiguous(), Us.t().contiguous()
-    model = model.to(device=c.device, dtype=ann_dtype)
+    model = model.to(device=c.device, dtype=ann_dtype).eval()
+    ann = AnnEvaluator(model, n, ann_dtype)
     hist, iters, flags = _alloc_hist(c, nsteps)
     Ar, br, _, _, _, G = _workspace(c, n)
     st = _IterState(c, n)
@@ -318,13 +398,11 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
         qp = (U0 @ Up).contiguous()                                         # (:1197)
         st.begin_step()
         while True:
-            with torch.no_grad():
-                dN = ann_jacobian(model, qp.to(ann_dtype)).to(torch.float64)    # (B, nbar, n)
+            dN = ann.jacobian(qp)                                           # (B, nbar, n), fp32 like :1219
             dD = (Up.unsqueeze(0) + torch.matmul(Us, dN)).contiguous()      # U_p + U_s dN        (:1224)
             rom_reduce(c, dD, U0, G, proj, True, st.active, Ar, br, None)
             left = st.solve_update(3, Ar, br, None, qp, tol, max_it)        # q_p += dq           (:1237-1244)
-            with torch.no_grad():
-                qs = model(qp.to(ann_dtype)).to(torch.float64)
+            qs = ann.forward(qp)                                            # (:1241)
             U0 = (qp @ UpT + qs @ UsT).contiguous()                         # (:1242)
             if left == 0:
                 break

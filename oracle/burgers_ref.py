@@ -32,7 +32,7 @@ __all__ = [
     "forcing_vector", "supg_term", "tridiag_matvec", "tridiag_solve",
     "system_tridiag", "fom_burgers", "pod_prom_burgers", "get_sym", "get_dQ_dq",
     "pod_quadratic_manifold", "mlp_forward", "mlp_jacobian", "pod_ann_prom",
-    "pod_basis", "n_modes_for_tolerance", "compute_H", "build_Q",
+    "pod_basis", "n_modes_for_tolerance", "compute_H", "build_Q", "predict_on_fom_grid",
 ]
 
 
@@ -487,3 +487,17 @@ def compute_H(Q, Em, alpha):
     f = s2 / (s2 + alpha ** 2)
     Gamma = (VqT @ Em.T) / s[:, None]
     return ((Uq * f) @ Gamma).T
+
+
+# --------------------------------------------------------------------------
+# Non-intrusive decoder          (Non-Instrusive/predict_pod_ann.py:73-80)
+# --------------------------------------------------------------------------
+def predict_on_fom_grid(mu1, mu2, Nt, U_modes, weights, biases, mean, std):
+    """``Uhat = U_modes @ MLP(standardize([mu1, mu2, tau]))ᵀ`` with a float32 MLP."""
+    tau = np.linspace(0.0, 1.0, Nt)
+    Z = np.column_stack([np.full(Nt, mu1), np.full(Nt, mu2), tau])
+    std = np.array(std, dtype=np.float64).copy()
+    std[std == 0] = 1.0
+    Zs = ((Z - mean) / std).astype(np.float32)
+    Q = np.stack([mlp_forward(weights, biases, z) for z in Zs])
+    return U_modes @ Q.T.astype(np.float64)

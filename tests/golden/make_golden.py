@@ -251,10 +251,37 @@ def fx_ann():
          committed_first5=committed[:, :5], **arrs)
 
 
+def fx_nonintrusive():
+    """Decoder-only POD-ANN (Non-Instrusive/predict_pod_ann.py:73-80): state_dict weights (safe
+    loader), standardiser, modes, and the reference's own prediction for one test point."""
+    import torch
+    sys.path.insert(0, os.path.join(REF, "Non-Instrusive"))
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "Non-Instrusive"))
+    try:
+        import predict_pod_ann as ppa
+        U_modes = np.load(ppa.UMODES_PATH)
+        sc = np.load(ppa.SCALER_Z_NPZ)
+        mean, std = sc["mean"], sc["std"]
+        state = torch.load(ppa.MODEL_PT, map_location="cpu", weights_only=True)
+        model = ppa.make_mlp(3, U_modes.shape[1], [32, 64, 128], "elu", 0.0)
+        model.load_state_dict(state)
+        model.eval()
+        U_FOM = np.load(os.path.join(REF, "FEM/fem_testing_data/fem_simulation_mu1_4.750_mu2_0.0200.npy"))
+        Uhat = ppa.predict_on_fom_grid(4.75, 0.02, U_modes, model, mean, std, U_FOM)
+    finally:
+        os.chdir(cwd)
+    arrs = {k.replace(".", "_"): v.numpy() for k, v in state.items()}
+    save("nonintrusive_decoder.npz", U_modes=U_modes, mean=mean, std=std, mu1=4.75, mu2=0.02, Nt=U_FOM.shape[1],
+         Uhat_cols=Uhat[:, COLS], cols=COLS, rel_err_vs_fom=np.linalg.norm(U_FOM - Uhat) / np.linalg.norm(U_FOM),
+         **arrs)
+
+
 FIXTURES = {
     "fom_n256": fx_fom_n256, "fom_n1024": fx_fom_n1024, "fom_general": fx_fom_general,
     "committed_fom": fx_committed_fom, "committed_pod": fx_committed_pod, "pod_live": fx_pod_live,
     "committed_quadratic": fx_committed_quadratic, "quadratic_live": fx_quadratic_live, "ann": fx_ann,
+    "nonintrusive": fx_nonintrusive,
 }
 
 if __name__ == "__main__":

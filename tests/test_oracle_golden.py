@@ -123,3 +123,12 @@ def test_ann_forward_jacobian_and_prom():
                             g["U_p"], g["U_s"], Ws, bs, return_iters=True)
     # the reference evaluates the MLP and its Jacobian in fp32: parity is fp32-limited
     assert rel_l2(U, g["U"]) < 5e-6
+
+
+def test_nonintrusive_decoder():
+    g = load_golden("nonintrusive_decoder.npz")
+    Ws = [g[f"{i}_weight"] for i in (0, 2, 4, 6)]
+    bs = [g[f"{i}_bias"] for i in (0, 2, 4, 6)]
+    U = br.predict_on_fom_grid(float(g["mu1"]), float(g["mu2"]), int(g["Nt"]), g["U_modes"], Ws, bs, g["mean"], g["std"])
+    assert U.shape == (512, 501)
+    assert rel_l2(U[:, g["cols"]], g["Uhat_cols"]) < 1e-5          # fp32 MLP
