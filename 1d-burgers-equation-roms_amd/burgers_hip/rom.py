@@ -147,15 +147,26 @@ class _IterState:
         self.counter = torch.zeros((2,), **i32)
         self.dq = torch.zeros((c.B, n), dtype=torch.float64, device=c.device)
 
+    # Converged samples are skipped ON THE DEVICE (active mask), so the host does not have to
+    # look after every batched iteration: it polls after POLL_FIRST iterations of a time step
+    # and then every POLL_EVERY; an iteration launched on an all-converged batch is a no-op.
+    POLL_FIRST = 4
+    POLL_EVERY = 2
+
     def begin_step(self):
         self.active.fill_(1)
         self.k.zero_()
+        self.launched = 0
 
     def solve_update(self, mode, Ar, br, wtu, q, tol, max_it):
         """dq = solve(Ar, -br); q, iteration counters and the active mask updated on the device.
-        Returns the number of samples that need another iteration."""
+        Returns the number of samples that need another iteration (-1: not polled this time)."""
         c = self.c
-        self.counter.zero_()
+        self.launched += 1
+        poll = (self.launched >= max_it or self.launched == self.POLL_FIRST or
+                (self.launched > self.POLL_FIRST and (self.launched - self.POLL_FIRST) % self.POLL_EVERY == 0))
+        if poll:
+            self.counter[0:1].zero_()       # [1] (singular systems) keeps accumulating until read
         with torch.cuda.device(c.device):
             rc = c.L.bg_lu_solve_update(q.shape[1], c.B, _lib.ptr(Ar), _lib.ptr(br), mode,
                                         _lib.ptr(wtu) if wtu is not None else None, _lib.ptr(q), _lib.ptr(self.dq),
@@ -164,6 +175,8 @@ class _IterState:
         if rc == _lib.BG_ERR_UNSUPPORTED_R:
             raise NotImplementedError("bg_lu_solve covers n <= 64")
         _lib.check(rc, "bg_lu_solve_update")
+        if not poll:
+            return -1
         n_active, n_singular = self.counter.cpu().tolist()
         if n_singular:
             raise SingularReducedSystem("Singular matrix")

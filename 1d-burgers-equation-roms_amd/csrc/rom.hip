@@ -116,7 +116,7 @@ struct ReduceArgs {
     int N, B, r, proj, supg, lift_only, nonuniform;
 };
 
-template <int S, int NT>
+template <int S, int NT, int PROJ>
 __global__ __launch_bounds__(256, 1) void rom_reduce_kernel(ReduceArgs a)
 {
     constexpr int NPAD = 16 * S;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void rom_reduce_kernel(ReduceArgs a)
 #pragma unroll
             for (int t = 0; t < NT; ++t) Bf[t] = Y[t];
             Bf[NT - 1] = rcol_lane ? R : Bf[NT - 1];
-            if (a.proj == BG_PROJ_GALERKIN) {
+            if constexpr (PROJ == BG_PROJ_GALERKIN) {
 #pragma unroll
                 for (int ta = 0; ta < NT; ++ta)
 #pragma unroll
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void rom_reduce_kernel(ReduceArgs a)
 #pragma unroll
         for (int t = 0; t < NT; ++t) s_q[w][g][16 * t + c] = qp[t];
         __syncthreads();
-        const bool sym = a.proj != BG_PROJ_GALERKIN;
+        constexpr bool sym = PROJ != BG_PROJ_GALERKIN;
         for (int e = tid; e < r * (r + 1); e += 256) {
             const int row = e / (r + 1), col = e % (r + 1);
             int rr = row, cc = col;
@@ -494,7 +494,13 @@ static int rom_reduce_impl(int N, int B, int r, int projection, const double* x,
     hipStream_t st = (hipStream_t)stream;
     const int S = N <= 128 ? 8 : (N <= 256 ? 16 : 32);
     const int NT = (r + 1 + 15) / 16;     // room for the extra column that carries R
-#define BG_LAUNCH_REDUCE(SV, NTV) hipLaunchKernelGGL((rom_reduce_kernel<SV, NTV>), dim3(grid), dim3(256), 0, st, a)
+#define BG_LAUNCH_REDUCE(SV, NTV)                                                                              \
+    do {                                                                                                       \
+        if (projection == BG_PROJ_GALERKIN)                                                                    \
+            hipLaunchKernelGGL((rom_reduce_kernel<SV, NTV, BG_PROJ_GALERKIN>), dim3(grid), dim3(256), 0, st, a); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((rom_reduce_kernel<SV, NTV, BG_PROJ_LSPG>), dim3(grid), dim3(256), 0, st, a);     \
+    } while (0)
     switch (S * 10 + NT) {
         case 81: BG_LAUNCH_REDUCE(8, 1); break;
         case 82: BG_LAUNCH_REDUCE(8, 2); break;
