@@ -27,7 +27,8 @@ for _p in (REPO, PKG):
 import numpy as np
 import torch
 
-FP64_MFMA_PEAK_TF = 78.6      # MI355X dense fp64 matrix peak (= vector peak on CDNA4)
+FP64_MFMA_PEAK_TF = 78.6      # MI355X fp64 peak as priced by SURVEY 8d (vector = matrix figure)
+FP64_MFMA_MEASURED_TF = 33.3  # bare v_mfma_f64_16x16x4_f64 loop, every SIMD busy (tools/mfma_bench.hip): 128 cyc/MFMA
 SEED = 20251121
 
 
@@ -79,7 +80,8 @@ def main():
                 "batch": B, "N": N, "r": r, "time_steps": nT, "newton_steps": steps, "seconds": secs,
                 "iters_per_step": steps / (B * nT), "dtype": "f64", "data": "synthetic",
                 "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                             "frac": tf / FP64_MFMA_PEAK_TF, "algorithmic_flops_per_step": flops_per_step},
+                             "frac": tf / FP64_MFMA_PEAK_TF, "algorithmic_flops_per_step": flops_per_step,
+                             "measured_mfma_ceiling": FP64_MFMA_MEASURED_TF, "frac_of_measured_ceiling": tf / FP64_MFMA_MEASURED_TF},
                 "nonfinite": int((res.flags & 2).ne(0).sum().item()), "hit_cap": int((res.flags & 1).ne(0).sum().item())}
         if extra:
             line.update(extra)
