@@ -21,7 +21,7 @@ os.makedirs(dst, exist_ok=True)
 def short(n):
     return n if len(n) < 140 else n[:137] + "..."
 
-stats = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 avg_ns = None
 if stats:
     rows = list(csv.reader(open(stats[0])))
@@ -36,7 +36,7 @@ pm = {}
 with open(os.path.join(dst, f"{tag}_pmc.csv"), "w", newline="") as f:
     w = csv.writer(f); w.writerow(["counter", "dispatch_id", "value_KiB", "vgpr", "sgpr", "lds", "scratch", "duration_ns"])
     for name in ("fetch", "write"):
-        for p in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
+        for p in sorted(glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)[:1]:
             for r in csv.DictReader(open(p)):
                 if key in r["Kernel_Name"]:
                     w.writerow([r["Counter_Name"], r["Dispatch_Id"], r["Counter_Value"], r["VGPR_Count"], r["SGPR_Count"],
