@@ -82,7 +82,8 @@ class BurgersHipError(RuntimeError):
 
 
 def library_path():
-    return _build.LIB_PATH
+    # BG_LIB_PATH: load an experimental build of the same ABI (kernel A/B timing); default in-tree
+    return os.environ.get("BG_LIB_PATH") or _build.LIB_PATH
 
 
 def load(build_if_missing=False):

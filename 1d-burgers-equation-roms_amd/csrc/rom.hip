@@ -11,6 +11,7 @@
 // contractions over the whole batch and live on the host side (burgers_hip/rom.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "../../include/burgers_hip.h"
@@ -305,6 +306,237 @@ __global__ __launch_bounds__(256, 1) void rom_reduce_kernel(ReduceArgs a)
 }
 
 // ------------------------------------------------------------------------------------
+// rom_reduce4_kernel: the same fused assembly + projection on v_mfma_f64_4x4x4_4b_f64.
+//   Measured on gfx950 (tools/mfma_bench.hip): the 4-block 4x4x4 form issues every ~16 cycles
+//   (512 flop) = 31 flop/clk/SIMD, twice the rate of the 16x16x4 form (128 cycles, 2048 flop),
+//   and its 4-wide blocks waste no padding at r = 40.  Lane map found with one-hot operands
+//   (tools/mfma_layout_probe.hip, profiles/r01_mfma_f64_4x4x4_lane_map.txt):
+//       A: lane = 16 k + 4 blk + i      B: lane = 16 k + 4 blk + j      D: lane = 16 i + 4 blk + j
+//   The four blocks of one instruction work on the SAME pair (a, b) of 4-column blocks of the
+//   output but on different mesh rows (K is split over k AND blk): "owner" o = 16 wave + (lane>>2)
+//   owns the S consecutive rows [o S, o S + S), lane t = lane & 3 holds W[row][4 c + t] for every
+//   column block c, so neighbouring rows are again the same lane's adjacent registers.  One extra
+//   B block [R, u, 0, 0] yields br and W^T u.  The four block partials of every pair are summed at
+//   the end with two DPP row shifts, the four waves through LDS.
+// ------------------------------------------------------------------------------------
+template <int NB, int PROJ, bool WTU>
+struct Pairs4 {
+    static constexpr int main_pairs = (PROJ == BG_PROJ_GALERKIN) ? NB * (NB + 1) : NB * (NB + 1) / 2 + NB;
+    static constexpr int total = main_pairs + ((PROJ != BG_PROJ_GALERKIN && WTU) ? NB : 0);
+};
+
+template <int S, int NB, int PROJ, bool WTU>
+__global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
+{
+    constexpr int NPAD = 64 * S;
+    constexpr int NPAIR = Pairs4<NB, PROJ, WTU>::total;
+    constexpr int RW = 4 * NB;                   // padded reduced dimension
+    constexpr bool GAL = PROJ == BG_PROJ_GALERKIN;
+    __shared__ double s_u[NPAD + 2];
+    __shared__ double s_coef[NPAD][4];
+    __shared__ double s_red[5][RW][RW + 4];      // per-wave  Ar | [br, W^T u (Galerkin), 0, 0]; [4] = dump for idle lanes
+    __shared__ double s_wtu[5][RW];              // per-wave  W^T u (LSPG); [4] = dump
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int t = lane & 3, owner = 16 * w + (lane >> 2);
+    const int N = a.N, r = a.r;
+    const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
+    const MeshConst mc = make_mesh_const(h, a.dt, a.E, a.supg);
+    const int rowbase = owner * S;
+
+    double frag[NB][S + 2];                      // W[rowbase + s - 1][4 c + t]
+    bool have_frags = false;
+
+    for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
+        if (a.active && a.active[smp] == 0) continue;          // workgroup-uniform
+        if (a.w_stride != 0 || !have_frags) {
+            const double* Wp = a.W + (size_t)smp * (size_t)a.w_stride;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const int col = 4 * c + t;
+#pragma unroll
+                for (int s = 0; s < S + 2; ++s) {
+                    const int i = rowbase + s - 1;
+                    frag[c][s] = (i >= 0 && i < N && col < r) ? Wp[(size_t)i * r + col] : 0.0;
+                }
+            }
+            have_frags = true;
+        }
+        // ---- stage u (from HBM, or lifted u = W q from the register-resident basis) ----------
+        if (a.q_in) {
+            double qv[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const int col = 4 * c + t;
+                qv[c] = col < r ? a.q_in[(size_t)smp * r + col] : 0.0;
+            }
+            if (tid == 0) { s_u[0] = 0.0; s_u[NPAD + 1] = 0.0; }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                double p = 0.0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) p = __builtin_fma(frag[c][s + 1], qv[c], p);
+                p += dpp_mov<0xB1>(p);             // quad_perm [1,0,3,2]: sum over the four t lanes
+                p += dpp_mov<0x4E>(p);             // quad_perm [2,3,0,1]
+                if (t == 0) {
+                    const int i = rowbase + s;
+                    s_u[i + 1] = p;
+                    if (i < N) a.Uout[(size_t)smp * N + i] = p;
+                }
+            }
+        } else {
+            const double* up_ = a.U + (size_t)smp * N;
+            for (int i = tid; i < NPAD + 2; i += 256) {
+                const int gi = i - 1;
+                s_u[i] = (gi >= 0 && gi < N) ? up_[gi] : 0.0;
+            }
+        }
+        __syncthreads();
+        if (a.lift_only) continue;                               // workgroup-uniform
+        // ---- assembly into LDS (same arithmetic as rom_reduce_kernel) -----------------------
+        const double mu1 = a.mu1[smp];
+        for (int i = tid; i < NPAD; i += 256) {
+            double lo = 0.0, di = 1.0, up = 0.0, rhs = 0.0;
+            if (i < N) {
+                const double um = s_u[i], u0 = s_u[i + 1], ur = s_u[i + 2];
+                const double gi = a.G[(size_t)smp * N + i];
+                double aoffL = mc.aoff, aoffR = mc.aoff, ddL = mc.dd1, ddR = mc.dd1;
+                if (a.nonuniform && i > 0) {
+                    const double hl = a.x[i] - a.x[i - 1];
+                    aoffL = hl / 6.0 - a.dt * a.E / hl; ddL = hl / 3.0 + a.dt * a.E / hl;
+                    if (i < N - 1) {
+                        const double hr = a.x[i + 1] - a.x[i];
+                        aoffR = hr / 6.0 - a.dt * a.E / hr; ddR = hr / 3.0 + a.dt * a.E / hr;
+                    }
+                }
+                if (i == 0) {
+                    rhs = mu1 - u0;
+                } else {
+                    const double wl = um + u0;
+                    lo = __builtin_fma(-mc.dt6, wl + u0, aoffL);
+                    const double tl = __builtin_fma(wl, u0 - um, -a.hfs[(size_t)smp * N + i - 1]);
+                    const double sl = tl * rcp(fmax(fabs(wl), 2.0e-10));
+                    double b = __builtin_fma(-mc.kap, sl, gi);
+                    if (i < N - 1) {
+                        const double wr = u0 + ur;
+                        up = __builtin_fma(mc.dt6, wr + u0, aoffR);
+                        di = __builtin_fma(mc.dt6, um - ur, ddL + ddR);
+                        const double tr = __builtin_fma(wr, ur - u0, -a.hfs[(size_t)smp * N + i]);
+                        const double sr = tr * rcp(fmax(fabs(wr), 2.0e-10));
+                        b = __builtin_fma(mc.kap, sr, b);
+                    } else {
+                        di = __builtin_fma(mc.dt6, wl + u0, ddL);
+                    }
+                    rhs = __builtin_fma(-lo, um, b);
+                    rhs = __builtin_fma(-di, u0, rhs);
+                    rhs = __builtin_fma(-up, ur, rhs);
+                }
+            }
+            s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = -rhs;   // [3] = R
+        }
+        __syncthreads();
+        // ---- MFMA contraction: every step feeds 16 mesh rows per wave ---------------------------
+        double acc[NPAIR];
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) acc[p] = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int i = rowbase + s;
+            const double lo = s_coef[i][0], di = s_coef[i][1], up = s_coef[i][2], R = s_coef[i][3];
+            const double ui = s_u[i + 1];
+            double Y[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                double y = lo * frag[c][s];
+                y = __builtin_fma(di, frag[c][s + 1], y);
+                y = __builtin_fma(up, frag[c][s + 2], y);
+                Y[c] = y;
+            }
+            const double X = (t == 0) ? R : ((t == 1) ? ui : 0.0);      // extra B block [R, u, 0, 0]
+            int p = 0;
+            if constexpr (GAL) {
+#pragma unroll
+                for (int ca = 0; ca < NB; ++ca) {
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb, ++p)
+                        acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s + 1], Y[cb], acc[p], 0, 0, 0);
+                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s + 1], X, acc[p], 0, 0, 0);
+                    ++p;
+                }
+            } else {
+#pragma unroll
+                for (int ca = 0; ca < NB; ++ca) {
+#pragma unroll
+                    for (int cb = ca; cb < NB; ++cb, ++p)
+                        acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(Y[ca], Y[cb], acc[p], 0, 0, 0);
+                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(Y[ca], X, acc[p], 0, 0, 0);
+                    ++p;
+                }
+                if constexpr (WTU) {
+#pragma unroll
+                    for (int ca = 0; ca < NB; ++ca, ++p)
+                        acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s + 1], X, acc[p], 0, 0, 0);
+                }
+            }
+        }
+        // ---- sum the four block partials of every pair (lanes differing in bits 2..3) -----------
+        {
+            const int oi = lane >> 4, oj = lane & 3;
+            const bool writer = ((lane >> 2) & 3) == 3;
+            const int wslot = writer ? w : 4;            // idle lanes store into the dump slab: no branches
+            int p = 0;
+#pragma unroll
+            for (int ca = 0; ca < NB; ++ca) {
+#pragma unroll
+                for (int cb = (GAL ? 0 : ca); cb <= NB; ++cb, ++p) {
+                    double v = acc[p];
+                    v += dpp_mov<0x114>(v);          // row_shr:4
+                    v += dpp_mov<0x118>(v);          // row_shr:8 -> lanes with blk == 3 hold the sum
+                    s_red[wslot][4 * ca + oi][4 * cb + oj] = v;
+                }
+            }
+            if constexpr (!GAL && WTU) {
+#pragma unroll
+                for (int ca = 0; ca < NB; ++ca, ++p) {
+                    double v = acc[p];
+                    v += dpp_mov<0x114>(v);
+                    v += dpp_mov<0x118>(v);
+                    s_wtu[(writer && oj == 1) ? w : 4][4 * ca + oi] = v;
+                }
+            }
+        }
+        __syncthreads();
+        {   // thread (col = tid & 63, row phase = tid >> 6): no integer division, coalesced row stores
+            const int col = tid & 63;
+            if (col <= r) {
+                for (int row = tid >> 6; row < r; row += 4) {
+                    int rr = row, cc = (col < r) ? col : RW;             // br sits in column RW
+                    if (!GAL && col < r && (row >> 2) > (col >> 2)) { rr = col; cc = row; }   // mirror lower blocks
+                    const double v = (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
+                    if (col < r)
+                        a.Ar[((size_t)smp * r + row) * r + col] = v;
+                    else
+                        a.br[(size_t)smp * r + row] = v;
+                }
+            }
+        }
+        if (a.wtu) {
+            for (int j = tid; j < r; j += 256) {
+                double v;
+                if constexpr (GAL)
+                    v = (s_red[0][j][RW + 1] + s_red[1][j][RW + 1]) + (s_red[2][j][RW + 1] + s_red[3][j][RW + 1]);
+                else if constexpr (WTU)
+                    v = (s_wtu[0][j] + s_wtu[1][j]) + (s_wtu[2][j] + s_wtu[3][j]);
+                else
+                    v = 0.0;
+                a.wtu[(size_t)smp * r + j] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // bg_lu_solve: x = solve(A, sign * b), partial pivoting, one wavefront per system.
 //   lane i holds row i of [A | b]; rows are never moved: the pivot of step k is the
 //   not-yet-used lane with the largest |a[k]| (LAPACK gesv's choice up to ties in the
@@ -492,6 +724,37 @@ static int rom_reduce_impl(int N, int B, int r, int projection, const double* x,
         cus = 256;
     const int grid = B < cus ? B : cus;
     hipStream_t st = (hipStream_t)stream;
+    // fast path: v_mfma_f64_4x4x4_4b kernel, r <= 40 (accumulators and fragments must fit the register file)
+    if (r <= 40 && !getenv("BG_ROM_FORCE_16X16")) {
+        const int nb = r <= 8 ? 2 : (r <= 16 ? 4 : (r <= 24 ? 6 : (r <= 32 ? 8 : 10)));
+        const bool want_wtu = wtu != nullptr;
+        const bool gal = projection == BG_PROJ_GALERKIN;
+        const int s4 = N <= 256 ? 4 : 8;
+#define BG_LAUNCH_R4(SV, NBV)                                                                                      \
+    do {                                                                                                           \
+        if (gal)                                                                                                   \
+            hipLaunchKernelGGL((rom_reduce4_kernel<SV, NBV, BG_PROJ_GALERKIN, true>), dim3(grid), dim3(256), 0, st, a); \
+        else if (want_wtu)                                                                                         \
+            hipLaunchKernelGGL((rom_reduce4_kernel<SV, NBV, BG_PROJ_LSPG, true>), dim3(grid), dim3(256), 0, st, a);    \
+        else                                                                                                       \
+            hipLaunchKernelGGL((rom_reduce4_kernel<SV, NBV, BG_PROJ_LSPG, false>), dim3(grid), dim3(256), 0, st, a);   \
+    } while (0)
+        switch (s4 * 100 + nb) {
+            case 402: BG_LAUNCH_R4(4, 2); break;
+            case 404: BG_LAUNCH_R4(4, 4); break;
+            case 406: BG_LAUNCH_R4(4, 6); break;
+            case 408: BG_LAUNCH_R4(4, 8); break;
+            case 410: BG_LAUNCH_R4(4, 10); break;
+            case 802: BG_LAUNCH_R4(8, 2); break;
+            case 804: BG_LAUNCH_R4(8, 4); break;
+            case 806: BG_LAUNCH_R4(8, 6); break;
+            case 808: BG_LAUNCH_R4(8, 8); break;
+            case 810: BG_LAUNCH_R4(8, 10); break;
+            default: return BG_ERR_UNSUPPORTED_R;
+        }
+#undef BG_LAUNCH_R4
+        return check_launch_rom();
+    }
     const int S = N <= 128 ? 8 : (N <= 256 ? 16 : 32);
     const int NT = (r + 1 + 15) / 16;     // room for the extra column that carries R
 #define BG_LAUNCH_REDUCE(SV, NTV)                                                                              \
