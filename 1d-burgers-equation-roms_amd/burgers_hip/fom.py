@@ -133,3 +133,29 @@ def transpose_batched(t):
                                         _lib.stream_ptr(device))
             _lib.check(rc, "bg_transpose_batched")
     return out
+
+
+def fd_run(a, b, N, u0, mu1, mu2, dt, nsteps, max_iter=30, tol=1e-8, device=None):
+    """Batched ``FDBurgers.fom_burgers_newton`` (FD/fd_burgers.py:59-107) on the mesh linspace(a, b, N)."""
+    L = _lib.load()
+    device = _lib.require_device(device)
+    Xd = _as_dev(np.linspace(a, b, N), device)
+    mu1d = _as_dev(mu1, device).reshape(-1)
+    mu2d = _as_dev(mu2, device).reshape(-1)
+    B = max(mu1d.numel(), mu2d.numel())
+    mu1d, mu2d = mu1d.expand(B).contiguous(), mu2d.expand(B).contiguous()
+    u0d = _as_dev(u0, device)
+    if u0d.dim() == 1:
+        u0d = u0d.unsqueeze(0)
+    if u0d.shape[-1] != N:
+        raise ValueError(f"U0 has {u0d.shape[-1]} entries per sample, mesh has {N}")
+    u0d = u0d.expand(B, N).contiguous()
+    hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
+    iters = torch.empty((B, nsteps), dtype=torch.int32, device=device)
+    flags = torch.empty((B,), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        rc = L.bg_fd_run(N, B, int(nsteps), _lib.ptr(Xd), _lib.ptr(u0d), _lib.ptr(mu1d), _lib.ptr(mu2d), float(dt),
+                         float(tol), int(max_iter), _lib.ptr(hist), _lib.ptr(iters), _lib.ptr(flags),
+                         _lib.stream_ptr(device))
+    _lib.check(rc, "bg_fd_run")
+    return FomResult(hist, iters, flags)

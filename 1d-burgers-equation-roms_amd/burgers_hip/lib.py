@@ -47,6 +47,9 @@ _SIGNATURES = {
                                         c_double_p, c_double_p, ctypes.c_void_p]),
     "bg_transpose_batched": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
                                             c_double_p, ctypes.c_void_p]),
+    "bg_fd_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                 c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_double_p, c_int_p,
+                                 c_int_p, ctypes.c_void_p]),
     "bg_rom_max_n": (ctypes.c_int, []),
     "bg_rom_max_r": (ctypes.c_int, []),
     "bg_forcing_setup": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_double,

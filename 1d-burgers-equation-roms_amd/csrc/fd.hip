@@ -1,0 +1,165 @@
+// fd.hip -- fused batched finite-difference true-Newton stepper (widening row f.4 of SURVEY 8).
+//
+// Replaces FDBurgers.fom_burgers_newton with the analytical Jacobian (reference
+// FD/fd_burgers.py:59-107; residual :28-35, Jacobian :37-44, boundary values :19-22).
+// Same skeleton as the FEM kernel: one wavefront per (mu1, mu2) sample for the whole time loop,
+// rows in registers, the tridiagonal Newton system solved by the Wang + PCR solver of
+// fom_device.hpp.  The Jacobian is diagonally dominant here (1/dt + 2 nu/dx^2 on the diagonal),
+// so pivot-free elimination is safe.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/burgers_hip.h"
+#include "fom_device.hpp"
+
+namespace {
+
+using namespace bg;
+
+struct FdArgs {
+    const double* x;
+    const double* u0;
+    const double* mu1;
+    const double* mu2;
+    double* hist;
+    int32_t* iters;
+    int32_t* flags;
+    double dt, tol;
+    int N, B, nsteps, max_it;
+};
+
+__device__ __forceinline__ double wave_max(double v)
+{
+    v = fmax(v, dpp_mov<0x111>(v));
+    v = fmax(v, dpp_mov<0x112>(v));
+    v = fmax(v, dpp_mov<0x114>(v));
+    v = fmax(v, dpp_mov<0x118>(v));
+    v = fmax(v, dpp_mov<0x142, 0xA>(v));
+    v = fmax(v, dpp_mov<0x143, 0xC>(v));
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// boundary values of the reference's apply_dirichlet_bc: U[0] = mu1, U[-1] = U[-2]
+template <int R>
+__device__ __forceinline__ void apply_bc(double (&u)[R], int N, int row0, double mu1)
+{
+    const double uL = from_lane_below(u[R - 1]);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int i = row0 + j;
+        const double um = (j == 0) ? uL : u[j - 1];
+        u[j] = (i == 0) ? mu1 : ((i == N - 1) ? um : u[j]);
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256, 1) void fd_fused_kernel(FdArgs a)
+{
+    const int lane = lane_id();
+    const int s = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (s >= a.B) return;
+    const int N = a.N, row0 = lane * R;
+    const double dx = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
+    const double idt = 1.0 / a.dt, i2dx = 1.0 / (2.0 * dx), idx2 = 1.0 / (dx * dx);
+    const double mu1 = a.mu1[s], mu2 = a.mu2[s];
+    double u[R], src[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int i = row0 + j;
+        u[j] = (i < N) ? a.u0[(size_t)s * N + i] : 0.0;
+        src[j] = (i < N) ? 0.02 * exp(mu2 * a.x[i]) : 0.0;
+    }
+    apply_bc<R>(u, N, row0, mu1);
+    double* hist = a.hist + (size_t)s * (size_t)(a.nsteps + 1) * (size_t)N;
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+        if (row0 + j < N) hist[row0 + j] = u[j];
+
+    int flags = 0;
+    for (int step = 0; step < a.nsteps; ++step) {
+        double uprev[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) uprev[j] = u[j];
+        int k = 0;
+        bool converged = false;
+        for (int it = 0; it < a.max_it; ++it) {
+            apply_bc<R>(u, N, row0, mu1);
+            const double uL = from_lane_below(u[R - 1]);
+            const double uR = from_lane_above(u[0]);
+            double mloc = 0.0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int i = row0 + j;
+                mloc = (i >= 1 && i <= N - 2) ? fmax(mloc, fabs(u[j])) : mloc;
+            }
+            const double umax_int = wave_max(mloc);                 // max |U_guess[1:-1]|
+            const double nu = 0.25 * dx * fmax(umax_int, fabs(mu1));  // max over ALL entries (U[-1] = U[-2])
+            const double nud = nu * idx2;
+            double lo[R], di[R], up[R], rhs[R];
+            double rloc = 0.0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int i = row0 + j;
+                const double um = (j == 0) ? uL : u[j - 1];
+                const double ur = (j == R - 1) ? uR : u[j + 1];
+                const bool interior = (i >= 1) && (i <= N - 2);
+                const double conv = (0.5 * ur * ur - 0.5 * um * um) * i2dx;
+                const double diff = nu * ((ur - 2.0 * u[j]) + um) * idx2;
+                const double Ri = (u[j] - uprev[j]) * idt + conv - src[j] - diff;
+                rloc = interior ? fmax(rloc, fabs(Ri)) : rloc;
+                lo[j] = (interior && i > 1) ? (-um * i2dx - nud) : 0.0;
+                up[j] = (interior && i < N - 2) ? (ur * i2dx - nud) : 0.0;
+                di[j] = interior ? (idt + 2.0 * nud) : 1.0;
+                rhs[j] = interior ? -Ri : 0.0;
+            }
+            const double res = wave_max(rloc);
+            if (res < a.tol) { converged = true; break; }          // wave-uniform
+            tridiag_solve<R>(lo, di, up, rhs);
+            double dloc = 0.0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                dloc = fmax(dloc, fabs(rhs[j]));
+                u[j] += rhs[j];
+            }
+            const double rel = wave_max(dloc) / fmax(umax_int, 1e-15);
+            ++k;
+            if (!(rel - rel == 0.0)) flags |= BG_FLAG_NONFINITE;
+            if (rel < a.tol) { converged = true; break; }
+        }
+        if (!converged) flags |= BG_FLAG_HIT_CAP;
+        apply_bc<R>(u, N, row0, mu1);
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (row0 + j < N) hist[(size_t)(step + 1) * N + row0 + j] = u[j];
+        if (lane == 0) a.iters[(size_t)s * a.nsteps + step] = k;
+    }
+    if (lane == 0) a.flags[s] = flags;
+}
+
+}  // namespace
+
+extern "C" int bg_fd_run(int N, int B, int nsteps, const double* x, const double* u0, const double* mu1,
+                         const double* mu2, double dt, double tol, int max_it, double* hist, int32_t* iters,
+                         int32_t* flags, void* stream)
+{
+    if (N < 3 || B < 0 || nsteps < 0 || max_it < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
+    if (B == 0) return BG_OK;
+    if (!x || !u0 || !mu1 || !mu2 || !hist || !flags || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
+    if (N > 1024) return BG_ERR_UNSUPPORTED_N;
+    FdArgs a{x, u0, mu1, mu2, hist, iters, flags, dt, tol, N, B, nsteps, max_it};
+    const dim3 grid((B + 3) / 4), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int r = (N + 63) / 64;
+#define BG_FD(RV) hipLaunchKernelGGL((fd_fused_kernel<RV>), grid, block, 0, st, a)
+    if (r <= 1) BG_FD(1);
+    else if (r <= 2) BG_FD(2);
+    else if (r <= 4) BG_FD(4);
+    else if (r <= 8) BG_FD(8);
+    else if (r <= 12) BG_FD(12);
+    else BG_FD(16);
+#undef BG_FD
+    return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_LAUNCH;
+}

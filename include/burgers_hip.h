@@ -169,6 +169,18 @@ int bg_lu_solve_update(int n, int B, const double *A, const double *rhs, int mod
                        double *q, double *dq, double tol, int max_it, int32_t *active, int32_t *iters,
                        int32_t *flags, int32_t *counter, int32_t *info, void *stream);
 
+/* =================================================================================
+ * bg_fd_run -- batched replacement of FDBurgers.fom_burgers_newton (analytical Jacobian)
+ *   reference: FD/fd_burgers.py:59-107 (time + Newton loops), residual :28-35, Jacobian :37-44,
+ *   boundary values :19-22 (U[0] = mu1, U[-1] = U[-2]).  Central differences with the lagged
+ *   artificial viscosity nu = 0.25 dx max|U|; stop on max|R| < tol or max|dU|/max|U| < tol.
+ *   Arrays as in bg_fom_run; x must be the linspace(a, b, N) of the reference; N <= 1024.
+ *   iters[b][t] = Newton solves taken in step t; flags: BG_FLAG_HIT_CAP when max_it ran out.
+ * ================================================================================= */
+int bg_fd_run(int N, int B, int nsteps, const double *x, const double *u0, const double *mu1,
+              const double *mu2, double dt, double tol, int max_it, double *hist, int32_t *iters,
+              int32_t *flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

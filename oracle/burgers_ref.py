@@ -32,7 +32,7 @@ __all__ = [
     "forcing_vector", "supg_term", "tridiag_matvec", "tridiag_solve",
     "system_tridiag", "fom_burgers", "pod_prom_burgers", "get_sym", "get_dQ_dq",
     "pod_quadratic_manifold", "mlp_forward", "mlp_jacobian", "pod_ann_prom",
-    "pod_basis", "n_modes_for_tolerance", "compute_H", "build_Q", "predict_on_fom_grid",
+    "pod_basis", "n_modes_for_tolerance", "compute_H", "build_Q", "predict_on_fom_grid", "fd_newton",
 ]
 
 
@@ -501,3 +501,50 @@ def predict_on_fom_grid(mu1, mu2, Nt, U_modes, weights, biases, mean, std):
     Zs = ((Z - mean) / std).astype(np.float32)
     Q = np.stack([mlp_forward(weights, biases, z) for z in Zs])
     return U_modes @ Q.T.astype(np.float64)
+
+
+# --------------------------------------------------------------------------
+# Finite-difference true-Newton stepper          (FD/fd_burgers.py:14-107)
+# --------------------------------------------------------------------------
+def fd_newton(a, b, N, dt, n_steps, U0, mu1, mu2, max_iter=30, tol=1e-8, return_iters=False):
+    """``FDBurgers.fom_burgers_newton`` (analytical Jacobian): central differences, lagged
+    artificial viscosity ``nu = 0.25 dx max|U|``, backward Euler, Newton with the tridiagonal
+    Jacobian of FD/fd_burgers.py:36-43, stop on max residual or max relative update < tol."""
+    dx = (b - a) / (N - 1)
+    x = np.linspace(a, b, N)
+    s_src = 0.02 * np.exp(mu2 * x)
+    Uall = np.zeros((N, n_steps + 1))
+    Uc = np.array(U0, dtype=np.float64).copy()
+    Uc[0] = mu1; Uc[-1] = Uc[-2]
+    Uall[:, 0] = Uc
+    iters = np.zeros(n_steps, dtype=np.int32)
+    for step in range(n_steps):
+        Up = Uc.copy()
+        Ug = Up.copy()
+        k = 0
+        for it in range(max_iter):
+            Ug[0] = mu1; Ug[-1] = Ug[-2]
+            nu = 0.25 * dx * np.max(np.abs(Ug))
+            R = np.zeros(N)
+            conv = (0.5 * Ug[2:] ** 2 - 0.5 * Ug[:-2] ** 2) / (2 * dx)
+            diff = nu * (Ug[2:] - 2 * Ug[1:-1] + Ug[:-2]) / dx ** 2
+            R[1:-1] = (Ug[1:-1] - Up[1:-1]) / dt + conv - s_src[1:-1] - diff
+            if np.max(np.abs(R[1:-1])) < tol:
+                break
+            lo = np.zeros(N); di = np.ones(N); up = np.zeros(N)
+            lo[1:-1] = -Ug[:-2] / (2 * dx) - nu / dx ** 2
+            up[1:-1] = Ug[2:] / (2 * dx) - nu / dx ** 2
+            di[1:-1] = 1 / dt + 2 * nu / dx ** 2
+            lo[1] = 0.0; up[-2] = 0.0              # interior block J[1:-1, 1:-1]
+            dU = tridiag_solve(lo, di, up, -R)
+            dU[0] = 0.0; dU[-1] = 0.0
+            rel = np.max(np.abs(dU[1:-1])) / max(np.max(np.abs(Ug[1:-1])), 1e-15)
+            Ug = Ug + dU
+            k += 1
+            if rel < tol:
+                break
+        iters[step] = k
+        Uc = Ug.copy()
+        Uc[0] = mu1; Uc[-1] = Uc[-2]
+        Uall[:, step + 1] = Uc
+    return (Uall, iters) if return_iters else Uall

@@ -277,11 +277,27 @@ def fx_nonintrusive():
          **arrs)
 
 
+def fx_fd():
+    """FD true-Newton stepper (FD/fd_burgers.py): live runs + slices of the committed training data."""
+    sys.path.insert(0, os.path.join(REF, "FD"))
+    import fd_burgers
+    out = {}
+    for tag, (N, dt, nT, mu1, mu2) in {"n128": (128, 0.1, 12, 4.8, 0.021), "n512": (512, 0.05, 8, 5.5, 0.03)}.items():
+        fd = fd_burgers.FDBurgers(0.0, 100.0, N)
+        U, log = quiet(fd.fom_burgers_newton, dt, nT, np.ones(N), mu1, mu2)
+        its = np.array([blk.count("relative update") for blk in log.split("Time step")[1:]], dtype=np.int32)
+        out.update({f"U_{tag}": U, f"iters_{tag}": its, f"par_{tag}": np.array([N, dt, nT, mu1, mu2])})
+    c = np.load(os.path.join(REF, "FD/fd_training_data/fd_simulation_mu1_4.250_mu2_0.0150.npy"))
+    out["committed_first11"] = c[:, :11]
+    out["committed_cols"] = c[:, COLS]
+    save("fd_newton.npz", cols=COLS, **out)
+
+
 FIXTURES = {
     "fom_n256": fx_fom_n256, "fom_n1024": fx_fom_n1024, "fom_general": fx_fom_general,
     "committed_fom": fx_committed_fom, "committed_pod": fx_committed_pod, "pod_live": fx_pod_live,
     "committed_quadratic": fx_committed_quadratic, "quadratic_live": fx_quadratic_live, "ann": fx_ann,
-    "nonintrusive": fx_nonintrusive,
+    "nonintrusive": fx_nonintrusive, "fd": fx_fd,
 }
 
 if __name__ == "__main__":

@@ -204,3 +204,38 @@ def test_nonuniform_mesh_golden_and_oracle(hip):
         h, it, fl = _run(hip, X, np.ones(N), mu1, mu2, dt, 15, E=0.002)
         ho, ito = bc.fom_run(X, np.ones(N), mu1, mu2, dt, 15, E=0.002)
         assert rel_l2(h, ho) < TOL and np.array_equal(it, ito), N
+
+
+def test_fd_newton_stepper(hip):
+    """Widening row f.4: FDBurgers.fom_burgers_newton on the same wavefront-tridiagonal skeleton."""
+    from burgers_hip import fom
+    from fd_burgers import FDBurgers
+    g = load_golden("fd_newton.npz")
+    for tag in ("n128", "n512"):
+        N, dt, nT, mu1, mu2 = g["par_" + tag]
+        N, nT = int(N), int(nT)
+        res = fom.fd_run(0.0, 100.0, N, np.ones(N), mu1, mu2, dt, nT)
+        torch.cuda.synchronize()
+        assert rel_l2(res.hist[0].cpu().numpy().T, g["U_" + tag]) < TOL
+        assert np.array_equal(res.iters[0].cpu().numpy(), g["iters_" + tag])
+    # the reference's committed training snapshot, full 500 steps, through the drop-in class
+    fd = FDBurgers(0.0, 100.0, 512)
+    U = fd.fom_burgers_newton(0.05, 500, np.ones(512), 4.25, 0.015)
+    assert U.shape == (512, 501) and rel_l2(U[:, g["cols"]], g["committed_cols"]) < TOL
+    assert rel_l2(U[:, :11], g["committed_first11"]) < TOL
+    # batch against the oracle, sizes that need row masks, non-constant initial state
+    rng = np.random.default_rng(5)
+    for N in (100, 300, 1000, 1024):
+        B = 6
+        mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+        X = np.linspace(0, 100, N)
+        u0 = 1.0 + 0.3 * np.sin(np.outer(rng.uniform(0.5, 2.0, B), X / 100 * np.pi))
+        dt = 0.05 * 512 / N
+        res = fom.fd_run(0.0, 100.0, N, u0, mu1, mu2, dt, 12)
+        torch.cuda.synchronize()
+        for b in range(B):
+            Uo, ito = br.fd_newton(0.0, 100.0, N, dt, 12, u0[b], mu1[b], mu2[b], return_iters=True)
+            assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < TOL, (N, b)
+            assert np.array_equal(res.iters[b].cpu().numpy(), ito), (N, b)
+    with pytest.raises(NotImplementedError):
+        fd.fom_burgers_newton(0.05, 1, np.ones(512), 4.25, 0.015, use_fd_jacobian=True)

@@ -132,3 +132,13 @@ def test_nonintrusive_decoder():
     U = br.predict_on_fom_grid(float(g["mu1"]), float(g["mu2"]), int(g["Nt"]), g["U_modes"], Ws, bs, g["mean"], g["std"])
     assert U.shape == (512, 501)
     assert rel_l2(U[:, g["cols"]], g["Uhat_cols"]) < 1e-5          # fp32 MLP
+
+
+def test_fd_newton_live_and_committed():
+    g = load_golden("fd_newton.npz")
+    for tag in ("n128", "n512"):
+        N, dt, nT, mu1, mu2 = g["par_" + tag]
+        U, it = br.fd_newton(0.0, 100.0, int(N), dt, int(nT), np.ones(int(N)), mu1, mu2, return_iters=True)
+        assert rel_l2(U, g["U_" + tag]) < 1e-14 and np.array_equal(it, g["iters_" + tag])
+    U = br.fd_newton(0.0, 100.0, 512, 0.05, 10, np.ones(512), 4.25, 0.015)
+    assert rel_l2(U, g["committed_first11"]) < 1e-14        # FD/fd_training_data (committed by the reference)
