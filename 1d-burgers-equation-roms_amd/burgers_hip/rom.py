@@ -163,6 +163,7 @@ class _IterState:
         Returns the number of samples that need another iteration (-1: not polled this time)."""
         c = self.c
         self.launched += 1
+        self.active_before = self.active.bool()        # samples whose q this call updates
         poll = (self.launched >= max_it or self.launched == self.POLL_FIRST or
                 (self.launched > self.POLL_FIRST and (self.launched - self.POLL_FIRST) % self.POLL_EVERY == 0))
         if poll:
@@ -417,6 +418,83 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
             left = st.solve_update(3, Ar, br, None, qp, tol, max_it)        # q_p += dq           (:1237-1244)
             qs = ann.forward(qp)                                            # (:1241)
             U0 = (qp @ UpT + qs @ UsT).contiguous()                         # (:1242)
+            if left == 0:
+                break
+        iters[:, nt] = st.k
+        hist[:, nt + 1] = U0
+    flags |= st.flags
+    return FomResult(hist, iters, flags)
+
+
+# ----------------------------------------------------------------------- POD-RBF
+class RbfClosure:
+    """Scaled RBF closure q_s = unscale(k(|x - x_i|) @ W), x = scale(q_p), and its full-chain
+    Jacobian, batched over samples (FEM/fem_burgers.py:160-260): plain dense contractions."""
+
+    def __init__(self, X_train, W, eps, kernel, x_min, x_max, y_min, y_max, device):
+        if kernel not in ("gaussian", "imq"):
+            raise ValueError("kernel must be 'gaussian' or 'imq'.")
+        f = lambda a: _as_dev(np.asarray(a, dtype=np.float64), device)
+        self.Xt, self.W, self.eps, self.kernel = f(X_train), f(W), float(eps), kernel
+        self.x_min, self.y_min = f(x_min), f(y_min)
+        self.dx = f(x_max) - self.x_min
+        self.dx[self.dx < 1e-15] = 1.0
+        self.dy = f(y_max) - self.y_min
+        self.dy[self.dy < 1e-15] = 1.0
+        if self.W.shape != (self.Xt.shape[0], self.dy.numel()) or self.Xt.shape[1] != self.dx.numel():
+            raise ValueError("X_train must be (Ns, n) and W (Ns, nbar)")
+
+    def _diff_r2(self, qp):
+        xs = 2.0 * ((qp - self.x_min) / self.dx) - 1.0                # (B, n)
+        diff = xs.unsqueeze(1) - self.Xt.unsqueeze(0)                  # (B, Ns, n)
+        return diff, (diff * diff).sum(-1)
+
+    def value(self, qp):
+        _, r2 = self._diff_r2(qp)
+        r = torch.sqrt(r2)
+        k = torch.exp(-(self.eps * r) ** 2) if self.kernel == "gaussian" else 1.0 / torch.sqrt(1.0 + (self.eps * r) ** 2)
+        return 0.5 * (k @ self.W + 1.0) * self.dy + self.y_min         # (B, nbar)
+
+    def jacobian(self, qp):
+        diff, r2 = self._diff_r2(qp)
+        r = torch.sqrt(r2)
+        if self.kernel == "gaussian":
+            G = (-2.0 * self.eps ** 2) * (torch.exp(-(self.eps * r) ** 2).unsqueeze(-1) * diff)
+        else:
+            k = (1.0 + (self.eps ** 2) * (r ** 2)) ** (-0.5)
+            G = (-(self.eps ** 2)) * ((k ** 3).unsqueeze(-1) * diff)
+        J = torch.matmul(self.W.t(), G) * (2.0 / self.dx).reshape(1, 1, -1)     # (B, nbar, n)
+        return (0.5 * self.dy).reshape(1, -1, 1) * J
+
+
+def pod_rbf_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, X_train, W, epsilon, x_min, x_max, y_min, y_max,
+                projection="LSPG", kernel="gaussian", E=0.0, tol_newton=1e-6, max_newton=30, device=None):
+    """Batched ``pod_rbf_prom`` (FEM/fem_burgers.py:1278-1398)."""
+    p = projection.lower()
+    if p not in PROJ:
+        raise ValueError("projection must be 'LSPG' or 'Galerkin'.")
+    proj = PROJ[p]
+    c = _setup(X, u0, mu1, mu2, dt, E, device)
+    rbf = RbfClosure(X_train, W, epsilon, kernel, x_min, x_max, y_min, y_max, c.device)
+    Up, Us = _as_dev(U_p, c.device), _as_dev(U_s, c.device)
+    n = Up.shape[1]
+    UpT, UsT = Up.t().contiguous(), Us.t().contiguous()
+    hist, iters, flags = _alloc_hist(c, nsteps)
+    Ar, br, _, _, _, G = _workspace(c, n)
+    st = _IterState(c, n)
+    U0 = c.u0.clone()
+    q = torch.zeros((c.B, n), dtype=torch.float64, device=c.device)
+    for nt in range(nsteps):
+        _mass_rhs(c, U0, G)
+        st.begin_step()
+        while True:
+            qp = (U0 @ Up).contiguous()                                     # q_p = U_p^T U0        (:1352)
+            dD = (Up.unsqueeze(0) + torch.matmul(Us, rbf.jacobian(qp))).contiguous()     # (:1361)
+            rom_reduce(c, dD, U0, G, proj, True, st.active, Ar, br, None)
+            left = st.solve_update(1, Ar, br, qp, q, tol_newton, max_newton)   # q_new = q_p + dq, err = |dq|/|q_new|
+            act = st.active_before
+            U1 = q @ UpT + rbf.value(q) @ UsT                               # (:1378-1381)
+            U0 = torch.where(act[:, None], U1, U0).contiguous()
             if left == 0:
                 break
         iters[:, nt] = st.k

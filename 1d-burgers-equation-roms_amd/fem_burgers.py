@@ -115,3 +115,14 @@ class FEMBurgers:
                                np.asarray(U_p, dtype=np.float64), np.asarray(U_s, dtype=np.float64),
                                copy.deepcopy(model), projection=projection, E=E)
         return self._finish(res, batched)
+
+    # --------------------------------------------------------------------------- POD-RBF
+    def pod_rbf_prom(self, At, nTimeSteps, u0, mu1, E, mu2, U_p, U_s, X_train, W, epsilon,
+                     x_min, x_max, y_min, y_max, projection="LSPG", kernel="gaussian",
+                     tol_newton=1e-6, max_newton=30):
+        """POD-RBF PROM with the scaled Gaussian / IMQ closure (reference :1278-1398)."""
+        batched = self._batched(mu1, mu2)
+        res = _rom.pod_rbf_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps), U_p, U_s,
+                               X_train, W, epsilon, x_min, x_max, y_min, y_max, projection=projection,
+                               kernel=kernel, E=E, tol_newton=tol_newton, max_newton=max_newton)
+        return self._finish(res, batched)

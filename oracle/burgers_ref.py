@@ -32,7 +32,7 @@ __all__ = [
     "forcing_vector", "supg_term", "tridiag_matvec", "tridiag_solve",
     "system_tridiag", "fom_burgers", "pod_prom_burgers", "get_sym", "get_dQ_dq",
     "pod_quadratic_manifold", "mlp_forward", "mlp_jacobian", "pod_ann_prom",
-    "pod_basis", "n_modes_for_tolerance", "compute_H", "build_Q", "predict_on_fom_grid", "fd_newton",
+    "pod_basis", "n_modes_for_tolerance", "compute_H", "build_Q", "predict_on_fom_grid", "fd_newton", "rbf_value", "rbf_jacobian", "pod_rbf_prom",
 ]
 
 
@@ -548,3 +548,83 @@ def fd_newton(a, b, N, dt, n_steps, U0, mu1, mu2, max_iter=30, tol=1e-8, return_
         Uc[0] = mu1; Uc[-1] = Uc[-2]
         Uall[:, step + 1] = Uc
     return (Uall, iters) if return_iters else Uall
+
+
+# --------------------------------------------------------------------------
+# POD-RBF PROM                       (FEM/fem_burgers.py:160-260, 1278-1398)
+# --------------------------------------------------------------------------
+def _rbf_scale(q_p, x_min, x_max):
+    dx = (x_max - x_min).copy()
+    dx[dx < 1e-15] = 1.0
+    return 2.0 * ((q_p - x_min) / dx) - 1.0, dx
+
+
+def rbf_value(q_p, X_train, W, eps, kernel, x_min, x_max, y_min, y_max):
+    """``interpolate_with_rbf_scaled`` (:225-236): scale, kernel sum, unscale."""
+    xs, _ = _rbf_scale(q_p, x_min, x_max)
+    r = np.linalg.norm(xs[None, :] - X_train, axis=1)
+    k = np.exp(-(eps * r) ** 2) if kernel == "gaussian" else 1.0 / np.sqrt(1.0 + (eps * r) ** 2)
+    dy = (y_max - y_min).copy()
+    dy[dy < 1e-15] = 1.0
+    return 0.5 * (k @ W + 1.0) * dy + y_min
+
+
+def rbf_jacobian(q_p, X_train, W, eps, kernel, x_min, x_max, y_min, y_max):
+    """``compute_rbf_jacobian_full`` (:238-260): ``diag(dy/2) Wᵀ G diag(2/dx)``."""
+    xs, dx = _rbf_scale(q_p, x_min, x_max)
+    diff = xs[None, :] - X_train
+    r = np.linalg.norm(diff, axis=1)
+    if kernel == "gaussian":
+        k = np.exp(-(eps * r) ** 2)
+        G = (-2.0 * eps ** 2) * (k[:, None] * diff)
+    else:
+        k = (1.0 + (eps ** 2) * (r ** 2)) ** (-0.5)
+        G = (-(eps ** 2)) * ((k ** 3)[:, None] * diff)
+    dy = (y_max - y_min).copy()
+    dy[dy < 1e-15] = 1.0
+    J = (W.T @ G) * (2.0 / dx)[None, :]
+    return (0.5 * dy)[:, None] * J
+
+
+def pod_rbf_prom(X, At, nTimeSteps, u0, mu1, E, mu2, U_p, U_s, X_train, W, epsilon, x_min, x_max, y_min, y_max,
+                 projection="LSPG", kernel="gaussian", tol_newton=1e-6, max_newton=30, return_iters=False):
+    if kernel not in ("gaussian", "imq"):
+        raise ValueError("kernel must be 'gaussian' or 'imq'.")
+    proj = projection.lower()
+    if proj not in ("galerkin", "lspg"):
+        raise ValueError("projection must be 'LSPG' or 'Galerkin'.")
+    X = np.asarray(X, dtype=np.float64)
+    n = len(X)
+    U = np.zeros((n, nTimeSteps + 1))
+    U[:, 0] = u0
+    M3 = mass_tridiag(X)
+    K3 = diffusion_tridiag(X)
+    F = forcing_vector(X, mu2)
+    iters = np.zeros(nTimeSteps, dtype=np.int32)
+    rb = (X_train, W, epsilon, kernel, x_min, x_max, y_min, y_max)
+    for nstep in range(nTimeSteps):
+        U0 = U[:, nstep].copy()
+        Mun = tridiag_matvec(*M3, U[:, nstep])
+        err, it, U1 = 1.0, 0, U0
+        while err > tol_newton and it < max_newton:
+            C3 = convection_tridiag(X, U0)
+            S = supg_term(X, U0, mu2)
+            A3 = [m + At * (c + E * k) for m, c, k in zip(M3, C3, K3)]        # A = M + At*(C + E*K)   (:1338)
+            lo, di, up = [a.copy() for a in A3]
+            lo[0] = 0.0; di[0] = 1.0; up[0] = 0.0
+            b = Mun + At * (F - S)
+            b[0] = mu1
+            R = tridiag_matvec(lo, di, up, U0) - b
+            q_p = U_p.T @ U0
+            dD = U_p + U_s @ rbf_jacobian(q_p, *rb)
+            Ar, br = _reduce(lo, di, up, R, dD, proj)
+            dq = np.linalg.solve(Ar, -br)
+            q_new = q_p + dq
+            U1 = U_p @ q_new + U_s @ rbf_value(q_new, *rb)
+            denom = np.linalg.norm(q_new)
+            err = (np.linalg.norm(dq) / denom) if denom > 0 else np.linalg.norm(dq)
+            U0 = U1
+            it += 1
+        iters[nstep] = it
+        U[:, nstep + 1] = U1
+    return (U, iters) if return_iters else U

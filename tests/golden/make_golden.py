@@ -293,11 +293,43 @@ def fx_fd():
     save("fd_newton.npz", cols=COLS, **out)
 
 
+def fx_rbf():
+    """POD-RBF PROM (pod_rbf_prom :1278-1398).  The committed closure has 4501 centres (3.5 MB of text
+    artefacts), so the fixture carries a 300-centre Gaussian/IMQ closure fitted HERE on a subsample of the
+    reference's own training coordinates (Q_train / Qbar_train) and the reference's outputs for it."""
+    fb = ref_solver()
+    d = os.path.join(REF, "POD-RBF/rbf_training_simple")
+    U_p = np.load(os.path.join(d, "Phi_primary.npy")); U_s = np.load(os.path.join(d, "Phi_secondary.npy"))
+    Q = np.load(os.path.join(d, "Q_train.npy")); Qb = np.load(os.path.join(d, "Qbar_train.npy"))
+    if Q.shape[0] != 4501:
+        Q, Qb = Q.T, Qb.T
+    idx = np.linspace(0, Q.shape[0] - 1, 300).astype(int)
+    x_min, x_max = Q.min(0), Q.max(0); y_min, y_max = Qb.min(0), Qb.max(0)
+    Xs = 2.0 * (Q[idx] - x_min) / (x_max - x_min) - 1.0
+    Ys = 2.0 * (Qb[idx] - y_min) / (y_max - y_min) - 1.0
+    X, T = mesh(512)
+    out = dict(U_p=U_p, U_s=U_s, X_train=Xs, x_min=x_min, x_max=x_max, y_min=y_min, y_max=y_max)
+    r = np.linalg.norm(Xs[:, None, :] - Xs[None, :, :], axis=2)
+    for kernel, eps, proj in (("gaussian", 2.0, "LSPG"), ("imq", 1.5, "Galerkin")):
+        Kmat = np.exp(-(eps * r) ** 2) if kernel == "gaussian" else 1.0 / np.sqrt(1.0 + (eps * r) ** 2)
+        W = np.linalg.solve(Kmat + 1e-8 * np.eye(len(idx)), Ys)
+        fem = fb.FEMBurgers(X, T)
+        U, log = quiet(fem.pod_rbf_prom, 0.05, 4, np.ones(512), 4.75, 0.0, 0.02, U_p, U_s, Xs, W, eps,
+                       x_min, x_max, y_min, y_max, projection=proj, kernel=kernel, tol_newton=1e-6, max_newton=20)
+        its = np.array([blk.count("Newton it=") for blk in log.split("Time Step:")[1:]], dtype=np.int32)
+        qp = U_p.T @ U[:, 2]
+        out.update({f"W_{kernel}": W, f"eps_{kernel}": eps, f"U_{kernel}": U, f"iters_{kernel}": its,
+                    f"val_{kernel}": fb.interpolate_with_rbf_scaled(qp, Xs, W, eps, kernel, x_min, x_max, y_min, y_max),
+                    f"jac_{kernel}": fb.compute_rbf_jacobian_full(qp, Xs, W, eps, kernel, x_min, x_max, y_min, y_max),
+                    f"qp_{kernel}": qp})
+    save("rbf_n17.npz", At=0.05, nT=4, mu1=4.75, mu2=0.02, **out)
+
+
 FIXTURES = {
     "fom_n256": fx_fom_n256, "fom_n1024": fx_fom_n1024, "fom_general": fx_fom_general,
     "committed_fom": fx_committed_fom, "committed_pod": fx_committed_pod, "pod_live": fx_pod_live,
     "committed_quadratic": fx_committed_quadratic, "quadratic_live": fx_quadratic_live, "ann": fx_ann,
-    "nonintrusive": fx_nonintrusive, "fd": fx_fd,
+    "nonintrusive": fx_nonintrusive, "fd": fx_fd, "rbf": fx_rbf,
 }
 
 if __name__ == "__main__":

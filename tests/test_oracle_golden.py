@@ -142,3 +142,20 @@ def test_fd_newton_live_and_committed():
         assert rel_l2(U, g["U_" + tag]) < 1e-14 and np.array_equal(it, g["iters_" + tag])
     U = br.fd_newton(0.0, 100.0, 512, 0.05, 10, np.ones(512), 4.25, 0.015)
     assert rel_l2(U, g["committed_first11"]) < 1e-14        # FD/fd_training_data (committed by the reference)
+
+
+def test_pod_rbf_prom_live_reference():
+    g = load_golden("rbf_n17.npz")
+    X = np.linspace(0, 100, 512)
+    for kernel, proj in (("gaussian", "LSPG"), ("imq", "Galerkin")):
+        args = (g["X_train"], g["W_" + kernel], float(g["eps_" + kernel]), kernel, g["x_min"], g["x_max"], g["y_min"], g["y_max"])
+        assert np.abs(br.rbf_value(g["qp_" + kernel], *args) - g["val_" + kernel]).max() < 1e-12
+        assert np.abs(br.rbf_jacobian(g["qp_" + kernel], *args) - g["jac_" + kernel]).max() < 1e-10 * np.abs(g["jac_" + kernel]).max()
+        U, it = br.pod_rbf_prom(X, float(g["At"]), int(g["nT"]), np.ones(512), float(g["mu1"]), 0.0, float(g["mu2"]),
+                                g["U_p"], g["U_s"], g["X_train"], g["W_" + kernel], float(g["eps_" + kernel]),
+                                g["x_min"], g["x_max"], g["y_min"], g["y_max"], projection=proj, kernel=kernel,
+                                max_newton=20, return_iters=True)
+        assert rel_l2(U, g["U_" + kernel]) < 1e-11 and np.array_equal(it, g["iters_" + kernel])
+    with pytest.raises(ValueError):
+        br.pod_rbf_prom(X, 0.05, 1, np.ones(512), 4.75, 0.0, 0.02, g["U_p"], g["U_s"], g["X_train"], g["W_imq"], 1.0,
+                        g["x_min"], g["x_max"], g["y_min"], g["y_max"], kernel="multiquadric")

@@ -272,3 +272,31 @@ def test_nonintrusive_decoder_fp32_and_bf16(hip):
                                  g["mean"], g["std"], dtype=torch.bfloat16)
     err = rel_l2(Ub[0].cpu().numpy()[:, g["cols"]], g["Uhat_cols"])
     assert err < 5e-2, err                                           # bf16 tier: reported, loosely bounded
+
+
+def test_pod_rbf_prom_live_reference(hip):
+    """Widening row f.3: pod_rbf_prom with a 300-centre closure; both kernels, both projections.
+    The closure weights reach 3.6e2, which amplifies rounding in the decoder: tolerance 1e-9."""
+    from burgers_hip import rom
+    from fem_burgers import FEMBurgers
+    g = load_golden("rbf_n17.npz")
+    X, T = mesh(512)
+    for kernel, proj in (("gaussian", "LSPG"), ("imq", "Galerkin")):
+        args = (g["U_p"], g["U_s"], g["X_train"], g["W_" + kernel], float(g["eps_" + kernel]), g["x_min"], g["x_max"],
+                g["y_min"], g["y_max"])
+        res = rom.pod_rbf_run(X, np.ones(512), [float(g["mu1"]), 5.1], [float(g["mu2"]), 0.024], float(g["At"]),
+                              int(g["nT"]), *args, projection=proj, kernel=kernel, max_newton=20)
+        torch.cuda.synchronize()
+        assert rel_l2(res.hist[0].cpu().numpy().T, g["U_" + kernel]) < 1e-9
+        assert np.array_equal(res.iters[0].cpu().numpy(), g["iters_" + kernel])
+        Uo, ito = br.pod_rbf_prom(X, float(g["At"]), int(g["nT"]), np.ones(512), 5.1, 0.0, 0.024, *args,
+                                  projection=proj, kernel=kernel, max_newton=20, return_iters=True)
+        assert rel_l2(res.hist[1].cpu().numpy().T, Uo) < 1e-9 and np.array_equal(res.iters[1].cpu().numpy(), ito)
+    fem = FEMBurgers(X, T)
+    U = fem.pod_rbf_prom(0.05, 4, np.ones(512), 4.75, 0.0, 0.02, g["U_p"], g["U_s"], g["X_train"], g["W_gaussian"],
+                         float(g["eps_gaussian"]), g["x_min"], g["x_max"], g["y_min"], g["y_max"], projection="LSPG",
+                         kernel="gaussian", tol_newton=1e-6, max_newton=20)
+    assert U.shape == (512, 5) and rel_l2(U, g["U_gaussian"]) < 1e-9
+    with pytest.raises(ValueError):
+        fem.pod_rbf_prom(0.05, 1, np.ones(512), 4.75, 0.0, 0.02, g["U_p"], g["U_s"], g["X_train"], g["W_imq"], 1.0,
+                         g["x_min"], g["x_max"], g["y_min"], g["y_max"], kernel="multiquadric")
