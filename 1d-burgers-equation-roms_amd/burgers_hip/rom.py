@@ -1,17 +1,17 @@
 """Batched projection-ROM time-steppers (host orchestration over the C ABI).
 
-Each Picard / Gauss-Newton iteration of the whole batch is
-    bg_rom_reduce (HIP: assembly + fp64-MFMA projection)  ->  bg_lu_solve (HIP: pivoted r x r solve)
-    ->  family-specific update (plain dense contractions over the batch: torch / rocBLAS).
-Samples carry an ``active`` flag; converged samples are skipped by the kernels and frozen
-by the masked update, so every sample follows exactly the reference's own loop:
+Each Picard / Gauss-Newton iteration of the whole batch is two HIP launches,
+    bg_rom_reduce[_lifted]  (assembly + fp64-MFMA projection, for POD also the lift u = Phi q)
+    bg_lu_solve_update      (pivoted r x r solve + reduced-coordinate update + convergence bookkeeping)
+plus the family-specific decode / tangent, which are plain dense contractions over the batch
+(torch / rocBLAS).  Samples carry an ``active`` flag on the device; converged samples are
+skipped by the kernels, so every sample follows exactly the reference's own loop:
   pod_prom_burgers        FEM/fem_burgers.py:709-785
   pod_quadratic_manifold  FEM/fem_burgers.py:1081-1175
   pod_ann_prom            FEM/fem_burgers.py:1177-1251
 """
 from __future__ import annotations
 
-import ctypes
 from dataclasses import dataclass
 
 import numpy as np
@@ -184,14 +184,6 @@ class _IterState:
         return n_active
 
 
-def _poll(active, info):
-    """One host readback per batched iteration: (#active samples, any singular pivot)."""
-    s = torch.stack([active.sum(), (info != 0).sum().to(active.dtype)]).cpu()
-    if int(s[1]) != 0:
-        raise SingularReducedSystem("Singular matrix")
-    return int(s[0])
-
-
 def _alloc_hist(c, nsteps):
     hist = torch.empty((c.B, nsteps + 1, c.N), dtype=torch.float64, device=c.device)
     hist[:, 0] = c.u0
@@ -201,9 +193,9 @@ def _alloc_hist(c, nsteps):
 
 
 def _workspace(c, r):
+    """Reduced system Ar | br, W^T u and the per-step right-hand side G = M u^n + dt F."""
     f64 = dict(dtype=torch.float64, device=c.device)
     return (torch.zeros((c.B, r, r), **f64), torch.zeros((c.B, r), **f64), torch.zeros((c.B, r), **f64),
-            torch.zeros((c.B, r), **f64), torch.zeros((c.B,), dtype=torch.int32, device=c.device),
             torch.empty((c.B, c.N), **f64))
 
 
@@ -221,7 +213,7 @@ def pod_prom_run(X, u0, mu1, mu2, dt, nsteps, Phi, projection="Galerkin", E=0.0,
     r = Phid.shape[1]
     PhiT = Phid.t().contiguous()
     hist, iters, flags = _alloc_hist(c, nsteps)
-    Ar, br, wtu, _, _, G = _workspace(c, r)
+    Ar, br, wtu, G = _workspace(c, r)
     st = _IterState(c, r)
     q = torch.zeros((c.B, r), dtype=torch.float64, device=c.device)
     U0 = c.u0.clone()
@@ -279,7 +271,7 @@ def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0,
         return q @ PhiT + (q[:, I] * q[:, J]) @ HT
 
     hist, iters, flags = _alloc_hist(c, nsteps)
-    Ar, br, _, _, _, G = _workspace(c, n)
+    Ar, br, _, G = _workspace(c, n)
     st = _IterState(c, n)
     H3t = H3.t().contiguous()
     Un = c.u0.clone()
@@ -404,7 +396,7 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
     model = model.to(device=c.device, dtype=ann_dtype).eval()
     ann = AnnEvaluator(model, n, ann_dtype)
     hist, iters, flags = _alloc_hist(c, nsteps)
-    Ar, br, _, _, _, G = _workspace(c, n)
+    Ar, br, _, G = _workspace(c, n)
     st = _IterState(c, n)
     U0 = c.u0.clone()
     for nt in range(nsteps):
@@ -480,7 +472,7 @@ def pod_rbf_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, X_train, W, epsilon, x_mi
     n = Up.shape[1]
     UpT, UsT = Up.t().contiguous(), Us.t().contiguous()
     hist, iters, flags = _alloc_hist(c, nsteps)
-    Ar, br, _, _, _, G = _workspace(c, n)
+    Ar, br, _, G = _workspace(c, n)
     st = _IterState(c, n)
     U0 = c.u0.clone()
     q = torch.zeros((c.B, n), dtype=torch.float64, device=c.device)
