@@ -47,14 +47,15 @@ class _Common:
         return _lib.stream_ptr(self.device)
 
 
-def _setup(X, u0, mu1, mu2, dt, E, device):
+def _setup(X, u0, mu1, mu2, dt, E, device, max_n=None):
     L = _lib.load()
     device = _lib.require_device(device)
     mesh_opt = _lib.mesh_options(check_mesh(X), supg=False)
     Xd = _as_dev(X, device)
     N = Xd.numel()
-    if N > L.bg_rom_max_n():
-        raise NotImplementedError(f"ROM kernels cover N <= {L.bg_rom_max_n()} (got {N})")
+    max_n = L.bg_rom_max_n() if max_n is None else max_n
+    if N > max_n:
+        raise NotImplementedError(f"ROM kernels cover N <= {max_n} (got {N})")
     mu1d = _as_dev(mu1, device).reshape(-1)
     mu2d = _as_dev(mu2, device).reshape(-1)
     B = max(mu1d.numel(), mu2d.numel())
@@ -206,6 +207,10 @@ def pod_prom_run(X, u0, mu1, mu2, dt, nsteps, Phi, projection="Galerkin", E=0.0,
     if projection not in ("Galerkin", "LSPG"):
         raise ValueError(f"Projection method '{projection}' is not available. Please use 'Galerkin' or 'LSPG'.")
     proj = PROJ[projection.lower()]
+    L = _lib.load()
+    r_in, n_in = np.shape(Phi)[1], np.shape(Phi)[0]
+    if r_in > L.bg_rom_max_r() or n_in > L.bg_rom_max_n():
+        return _pod_prom_run_library(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E, tol, max_it, device)
     c = _setup(X, u0, mu1, mu2, dt, E, device)
     Phid = _as_dev(Phi, c.device)
     if Phid.shape[0] != c.N:
@@ -233,6 +238,56 @@ def pod_prom_run(X, u0, mu1, mu2, dt, nsteps, Phi, projection="Galerkin", E=0.0,
         iters[:, n] = st.k
         hist[:, n + 1] = U0
     flags |= st.flags
+    return FomResult(hist, iters, flags)
+
+
+def _pod_prom_run_library(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E, tol, max_it, device):
+    """POD PROM for bases beyond the register-resident MFMA kernels (r > 47 or N > 512; the thesis
+    also runs r = 96, 160, 227): bg_fom_assemble (HIP) for A(u), R(u), then the projection and
+    the reduced solve as plain library calls over the batch (rocBLAS GEMMs, rocSOLVER LU).
+    Same loop and stopping rule as the fused path; slower, but it keeps the API total."""
+    from . import fom as _fom
+    L = _lib.load()
+    c = _setup(X, u0, mu1, mu2, dt, E, device, max_n=L.bg_fom_max_n())
+    Xh = c.X.cpu().numpy()
+    Phid = _as_dev(Phi, c.device)
+    if Phid.shape[0] != c.N:
+        raise ValueError("Phi must have one row per mesh node")
+    PhiT = Phid.t().contiguous()
+    zrow = torch.zeros((1, Phid.shape[1]), dtype=torch.float64, device=c.device)
+    Phi_dn = torch.cat([zrow, Phid[:-1]], 0)              # row i holds Phi[i-1]
+    Phi_up = torch.cat([Phid[1:], zrow], 0)               # row i holds Phi[i+1]
+    hist, iters, flags = _alloc_hist(c, nsteps)
+    U0 = c.u0.clone()
+    for n in range(nsteps):
+        Un = U0.clone()
+        active = torch.ones((c.B,), dtype=torch.bool, device=c.device)
+        k = torch.zeros((c.B,), dtype=torch.int32, device=c.device)
+        while True:
+            lo, di, up, rhs = _fom.fom_assemble(Xh, U0, Un, c.mu1, c.mu2, c.dt, E=c.E, supg=True, device=c.device)
+            Y = di.unsqueeze(-1) * Phid + lo.unsqueeze(-1) * Phi_dn + up.unsqueeze(-1) * Phi_up     # A Phi, (B, N, r)
+            if proj == _lib.BG_PROJ_GALERKIN:
+                Ar = torch.matmul(PhiT, Y)                                   # Phi^T A Phi       (:756)
+                br = -(rhs @ Phid)                                           # Phi^T R, R = -rhs (:757)
+            else:
+                Ar = torch.matmul(Y.transpose(1, 2), Y)                      # (A Phi)^T (A Phi) (:761)
+                br = -torch.matmul(Y.transpose(1, 2), rhs.unsqueeze(-1)).squeeze(-1)
+            try:
+                dq = torch.linalg.solve(Ar, -br)
+            except RuntimeError as e:                                       # numpy raises LinAlgError here (:767)
+                raise SingularReducedSystem("Singular matrix") from e
+            q = U0 @ Phid + dq
+            U1 = q @ PhiT
+            err = torch.linalg.vector_norm(dq, dim=1) / torch.linalg.vector_norm(q, dim=1)
+            U0 = torch.where(active[:, None], U1, U0)
+            k += active.to(torch.int32)
+            flags |= (active & ~torch.isfinite(err)).to(torch.int32) * _lib.BG_FLAG_NONFINITE
+            active = active & (err > tol) & (k < max_it)
+            if not bool(active.any()):
+                break
+        flags |= (k >= max_it).to(torch.int32) * _lib.BG_FLAG_HIT_CAP
+        iters[:, n] = k
+        hist[:, n + 1] = U0
     return FomResult(hist, iters, flags)
 
 

@@ -325,11 +325,22 @@ def fx_rbf():
     save("rbf_n17.npz", At=0.05, nT=4, mu1=4.75, mu2=0.02, **out)
 
 
+def fx_committed_pod_r96():
+    """Committed 96-mode basis (tol 1e-04) and the first columns of its committed PROM outputs: pins the
+    large-r path (r beyond the register-resident MFMA kernels)."""
+    Phi = np.load(os.path.join(REF, "POD/modes/U_modes_tol_1e-04.npy"))
+    out = {"Phi": Phi}
+    for tag in ("galerkin", "lspg"):
+        a = np.load(os.path.join(REF, f"POD/Results_thesis/rom_solutions/U_PROM_tol_1e-04_mu1_4.750_mu2_0.0200_{tag}.npy"))
+        out["first9_" + tag] = a[:, :9]
+    save("committed_pod_r96.npz", **out)
+
+
 FIXTURES = {
     "fom_n256": fx_fom_n256, "fom_n1024": fx_fom_n1024, "fom_general": fx_fom_general,
     "committed_fom": fx_committed_fom, "committed_pod": fx_committed_pod, "pod_live": fx_pod_live,
     "committed_quadratic": fx_committed_quadratic, "quadratic_live": fx_quadratic_live, "ann": fx_ann,
-    "nonintrusive": fx_nonintrusive, "fd": fx_fd, "rbf": fx_rbf,
+    "nonintrusive": fx_nonintrusive, "fd": fx_fd, "rbf": fx_rbf, "committed_pod_r96": fx_committed_pod_r96,
 }
 
 if __name__ == "__main__":

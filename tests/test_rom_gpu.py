@@ -300,3 +300,18 @@ def test_pod_rbf_prom_live_reference(hip):
     with pytest.raises(ValueError):
         fem.pod_rbf_prom(0.05, 1, np.ones(512), 4.75, 0.0, 0.02, g["U_p"], g["U_s"], g["X_train"], g["W_imq"], 1.0,
                          g["x_min"], g["x_max"], g["y_min"], g["y_max"], kernel="multiquadric")
+
+
+def test_pod_prom_large_basis_library_path(hip):
+    """r = 96 (the thesis' tol 1e-04 basis) is beyond the register-resident kernels: HIP assembly +
+    library GEMM / LU path, against the reference's committed PROM outputs and the oracle."""
+    from burgers_hip import rom
+    g = load_golden("committed_pod_r96.npz")
+    X, _ = mesh(512)
+    assert g["Phi"].shape == (512, 96)
+    for tag, proj in (("galerkin", "Galerkin"), ("lspg", "LSPG")):
+        res = rom.pod_prom_run(X, np.ones(512), [4.75, 5.3], [0.02, 0.018], 0.05, 8, g["Phi"], projection=proj)
+        torch.cuda.synchronize()
+        assert rel_l2(res.hist[0].cpu().numpy().T, g["first9_" + tag]) < TOL
+        U, ito = br.pod_prom_burgers(X, 0.05, 8, np.ones(512), 5.3, 0.0, 0.018, g["Phi"], projection=proj, return_iters=True)
+        assert rel_l2(res.hist[1].cpu().numpy().T, U) < TOL and np.array_equal(res.iters[1].cpu().numpy(), ito)
