@@ -548,3 +548,59 @@ def pod_rbf_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, X_train, W, epsilon, x_mi
         hist[:, nt + 1] = U0
     flags |= st.flags
     return FomResult(hist, iters, flags)
+
+
+# --------------------------------------------------------------------- local POD
+def local_prom_run(X, u0, mu1, mu2, dt, nsteps, centers, local_bases, U_global, num_global_modes,
+                   projection="Galerkin", E=0.0, tol=1e-6, max_it=20, device=None):
+    """Batched ``local_prom_burgers`` (FEM/fem_burgers.py:979-1079): each sample picks, once per time
+    step, the local basis of the cluster whose centre is nearest to ``U_global[:, :m]^T u^n``
+    (= ``kmeans.predict``), then iterates like ``pod_prom_burgers`` in that basis.  The bases are
+    zero-padded to a common width and travel as per-sample W; padded reduced unknowns get a unit
+    diagonal so that their correction is exactly zero."""
+    if projection not in ("Galerkin", "LSPG"):
+        raise ValueError(f"Projection method '{projection}' is not available. Please use 'Galerkin' or 'LSPG'.")
+    proj = PROJ[projection.lower()]
+    c = _setup(X, u0, mu1, mu2, dt, E, device)
+    ids = sorted(local_bases.keys())
+    widths = [int(np.shape(local_bases[i])[1]) for i in ids]
+    rmax = max(widths)
+    if rmax > c.L.bg_rom_max_r():
+        raise NotImplementedError(f"local bases wider than {c.L.bg_rom_max_r()} modes are not covered")
+    stack = torch.zeros((len(ids), c.N, rmax), dtype=torch.float64, device=c.device)
+    for s_, (i, w_) in enumerate(zip(ids, widths)):
+        stack[s_, :, :w_] = _as_dev(local_bases[i], c.device)
+    slot_of = torch.full((max(ids) + 1,), -1, dtype=torch.long, device=c.device)
+    slot_of[torch.as_tensor(ids, device=c.device)] = torch.arange(len(ids), device=c.device)
+    width_t = torch.as_tensor(widths, device=c.device)
+    cen = _as_dev(centers, c.device)                                        # (n_clusters, m)
+    Ug = _as_dev(U_global, c.device)[:, :num_global_modes].contiguous()
+    col = torch.arange(rmax, device=c.device)
+    hist, iters, flags = _alloc_hist(c, nsteps)
+    Ar, br, wtu, G = _workspace(c, rmax)
+    st = _IterState(c, rmax)
+    q = torch.zeros((c.B, rmax), dtype=torch.float64, device=c.device)
+    U0 = c.u0.clone()
+    for n in range(nsteps):
+        _mass_rhs(c, U0, G)
+        qg = U0 @ Ug                                                          # (:1011)
+        cid = torch.cdist(qg, cen).argmin(dim=1)                              # kmeans.predict  (:1012)
+        slot = slot_of[cid]
+        if bool((slot < 0).any()):
+            raise KeyError("a predicted cluster has no local basis")
+        W = stack[slot].contiguous()                                          # (B, N, rmax)     (:1013)
+        pad = (col[None, :] >= width_t[slot][:, None]).to(torch.float64)      # 1 on padded reduced unknowns
+        st.begin_step()
+        while True:
+            rom_reduce(c, W, U0, G, proj, True, st.active, Ar, br, wtu)
+            Ar.diagonal(dim1=1, dim2=2).add_(pad * st.active[:, None].to(torch.float64))
+            left = st.solve_update(1, Ar, br, wtu, q, tol, max_it)           # q = Phi^T U0 + dq
+            act = st.active_before
+            U1 = torch.bmm(W, q.unsqueeze(-1)).squeeze(-1)                   # U1 = Phi q
+            U0 = torch.where(act[:, None], U1, U0).contiguous()
+            if left == 0:
+                break
+        iters[:, n] = st.k
+        hist[:, n + 1] = U0
+    flags |= st.flags
+    return FomResult(hist, iters, flags)

@@ -126,3 +126,15 @@ class FEMBurgers:
                                X_train, W, epsilon, x_min, x_max, y_min, y_max, projection=projection,
                                kernel=kernel, E=E, tol_newton=tol_newton, max_newton=max_newton)
         return self._finish(res, batched)
+
+    # ------------------------------------------------------------------------- local POD
+    def local_prom_burgers(self, At, nTimeSteps, u0, mu1, E, mu2, kmeans, local_bases, U_global,
+                           num_global_modes, projection="Galerkin"):
+        """Local (clustered) POD PROM (reference :979-1079).  ``kmeans`` is the fitted
+        scikit-learn KMeans of the reference (only ``cluster_centers_`` is used: ``predict`` is the
+        nearest centre), ``local_bases`` a dict cluster id -> (N, r_c) basis."""
+        batched = self._batched(mu1, mu2)
+        res = _rom.local_prom_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps),
+                                  np.asarray(kmeans.cluster_centers_, dtype=np.float64), local_bases, U_global,
+                                  int(num_global_modes), projection=projection, E=E)
+        return self._finish(res, batched)

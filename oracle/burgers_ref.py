@@ -32,7 +32,7 @@ __all__ = [
     "forcing_vector", "supg_term", "tridiag_matvec", "tridiag_solve",
     "system_tridiag", "fom_burgers", "pod_prom_burgers", "get_sym", "get_dQ_dq",
     "pod_quadratic_manifold", "mlp_forward", "mlp_jacobian", "pod_ann_prom",
-    "pod_basis", "n_modes_for_tolerance", "compute_H", "build_Q", "predict_on_fom_grid", "fd_newton", "rbf_value", "rbf_jacobian", "pod_rbf_prom",
+    "pod_basis", "n_modes_for_tolerance", "compute_H", "build_Q", "predict_on_fom_grid", "fd_newton", "rbf_value", "rbf_jacobian", "pod_rbf_prom", "local_prom_burgers",
 ]
 
 
@@ -628,3 +628,51 @@ def pod_rbf_prom(X, At, nTimeSteps, u0, mu1, E, mu2, U_p, U_s, X_train, W, epsil
         iters[nstep] = it
         U[:, nstep + 1] = U1
     return (U, iters) if return_iters else U
+
+
+# --------------------------------------------------------------------------
+# Local (clustered) POD PROM                     (FEM/fem_burgers.py:979-1079)
+# --------------------------------------------------------------------------
+def local_prom_burgers(X, At, nTimeSteps, u0, mu1, E, mu2, centers, local_bases, U_global, num_global_modes,
+                       projection="Galerkin", tol=1e-6, max_it=20, return_iters=False):
+    """``pod_prom_burgers`` with ONE local basis per time step: the cluster whose centre is nearest to
+    ``U_global[:, :m]ᵀ u^n`` (what ``kmeans.predict`` returns, :1011-1013)."""
+    if projection not in ("Galerkin", "LSPG"):
+        raise ValueError(f"Projection method '{projection}' is not available. Please use 'Galerkin' or 'LSPG'.")
+    proj = projection.lower()
+    X = np.asarray(X, dtype=np.float64)
+    n = len(X)
+    U = np.zeros((n, nTimeSteps + 1))
+    U[:, 0] = u0
+    M3 = mass_tridiag(X)
+    K3 = diffusion_tridiag(X)
+    F = forcing_vector(X, mu2)
+    Ug = U_global[:, :num_global_modes]
+    iters = np.zeros(nTimeSteps, dtype=np.int32)
+    clusters = np.zeros(nTimeSteps, dtype=np.int32)
+    for nstep in range(nTimeSteps):
+        Un = U[:, nstep]
+        U0 = Un
+        qg = Ug.T @ U0
+        cid = int(np.argmin(((centers - qg[None, :]) ** 2).sum(1)))
+        Phi = local_bases[cid]
+        clusters[nstep] = cid
+        err, k, U1 = 1.0, 0, Un
+        Mun = tridiag_matvec(*M3, Un)
+        while err > tol and k < max_it:
+            C3 = convection_tridiag(X, U0)
+            S = supg_term(X, U0, mu2)
+            lo, di, up = system_tridiag(M3, K3, C3, At, E)
+            b = Mun + At * F - At * S
+            b[0] = mu1
+            R = tridiag_matvec(lo, di, up, U0) - b
+            Ar, br = _reduce(lo, di, up, R, Phi, proj)
+            dq = np.linalg.solve(Ar, -br)
+            q = Phi.T @ U0 + dq
+            U1 = Phi @ q
+            err = np.linalg.norm(dq) / np.linalg.norm(q)
+            U0 = U1
+            k += 1
+        iters[nstep] = k
+        U[:, nstep + 1] = U1
+    return (U, iters, clusters) if return_iters else U

@@ -336,11 +336,52 @@ def fx_committed_pod_r96():
     save("committed_pod_r96.npz", **out)
 
 
+def fx_local_pod():
+    """Local POD PROM (local_prom_burgers :979-1079).  The committed cluster artefacts are pickles (never
+    loaded), so the fixture builds 4 clusters HERE from the reference's committed snapshots (nearest-centre
+    clustering in the first 12 global POD coordinates, one overlapping local basis per cluster) and records
+    the reference's output for them through a minimal stand-in for the fitted KMeans object."""
+    fb = ref_solver()
+    d = os.path.join(REF, "FEM/fem_training_data")
+    files = sorted(f for f in os.listdir(d) if f.startswith("fem_simulation_") and f.endswith(".npy"))
+    S = np.hstack([np.load(os.path.join(d, f))[:, ::4] for f in files])          # (512, 9*126)
+    Ug = np.linalg.svd(S, full_matrices=False)[0][:, :12]
+    Q = (Ug.T @ S).T
+    rng = np.random.default_rng(3)
+    centers = Q[rng.choice(len(Q), 4, replace=False)].copy()
+    for _ in range(25):                                                          # plain Lloyd iterations
+        lab = np.argmin(((Q[:, None, :] - centers[None]) ** 2).sum(2), 1)
+        centers = np.stack([Q[lab == c].mean(0) if np.any(lab == c) else centers[c] for c in range(4)])
+    lab = np.argmin(((Q[:, None, :] - centers[None]) ** 2).sum(2), 1)
+    d2 = ((Q[:, None, :] - centers[None]) ** 2).sum(2)
+    bases = {}
+    for c in range(4):
+        member = (lab == c) | (d2[:, c] < 1.5 * d2.min(1))                        # overlap with neighbours
+        Uc = np.linalg.svd(S[:, member], full_matrices=False)[0]
+        bases[c] = np.ascontiguousarray(Uc[:, :[14, 22, 30, 18][c]])
+
+    class NearestCentre:                                                          # kmeans.predict stand-in
+        cluster_centers_ = centers
+        def predict(self, q):
+            return np.argmin(((np.atleast_2d(q)[:, None, :] - centers[None]) ** 2).sum(2), 1)
+
+    X, T = mesh(512)
+    out = {"centers": centers, "U_global": Ug}
+    out.update({f"basis{c}": bases[c] for c in range(4)})
+    for proj in ("Galerkin", "LSPG"):
+        U, log = quiet(fb.FEMBurgers(X, T).local_prom_burgers, 0.05, 150, np.ones(512), 4.9, 0.0, 0.022, NearestCentre(),
+                       bases, Ug, 12, projection=proj)
+        out["U_" + proj] = U[:, ::5]
+        out["iters_" + proj] = iters_from_log(log)
+    save("local_pod.npz", At=0.05, nT=150, stride=5, mu1=4.9, mu2=0.022, **out)
+
+
 FIXTURES = {
     "fom_n256": fx_fom_n256, "fom_n1024": fx_fom_n1024, "fom_general": fx_fom_general,
     "committed_fom": fx_committed_fom, "committed_pod": fx_committed_pod, "pod_live": fx_pod_live,
     "committed_quadratic": fx_committed_quadratic, "quadratic_live": fx_quadratic_live, "ann": fx_ann,
     "nonintrusive": fx_nonintrusive, "fd": fx_fd, "rbf": fx_rbf, "committed_pod_r96": fx_committed_pod_r96,
+    "local_pod": fx_local_pod,
 }
 
 if __name__ == "__main__":

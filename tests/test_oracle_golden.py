@@ -159,3 +159,15 @@ def test_pod_rbf_prom_live_reference():
     with pytest.raises(ValueError):
         br.pod_rbf_prom(X, 0.05, 1, np.ones(512), 4.75, 0.0, 0.02, g["U_p"], g["U_s"], g["X_train"], g["W_imq"], 1.0,
                         g["x_min"], g["x_max"], g["y_min"], g["y_max"], kernel="multiquadric")
+
+
+def test_local_prom_live_reference():
+    g = load_golden("local_pod.npz")
+    X = np.linspace(0, 100, 512)
+    bases = {c: g[f"basis{c}"] for c in range(4)}
+    for proj in ("Galerkin", "LSPG"):
+        U, it, cl = br.local_prom_burgers(X, float(g["At"]), int(g["nT"]), np.ones(512), float(g["mu1"]), 0.0,
+                                          float(g["mu2"]), g["centers"], bases, g["U_global"], 12, projection=proj,
+                                          return_iters=True)
+        assert rel_l2(U[:, ::int(g["stride"])], g["U_" + proj]) < 1e-12 and np.array_equal(it, g["iters_" + proj])
+        assert len(np.unique(cl)) >= 2                     # the run really switches bases

@@ -315,3 +315,28 @@ def test_pod_prom_large_basis_library_path(hip):
         assert rel_l2(res.hist[0].cpu().numpy().T, g["first9_" + tag]) < TOL
         U, ito = br.pod_prom_burgers(X, 0.05, 8, np.ones(512), 5.3, 0.0, 0.018, g["Phi"], projection=proj, return_iters=True)
         assert rel_l2(res.hist[1].cpu().numpy().T, U) < TOL and np.array_equal(res.iters[1].cpu().numpy(), ito)
+
+
+def test_local_prom_live_reference(hip):
+    """Widening row f.2: local_prom_burgers, bases of different widths, a basis switch mid-run."""
+    from burgers_hip import rom
+    from fem_burgers import FEMBurgers
+    g = load_golden("local_pod.npz")
+    X, T = mesh(512)
+    bases = {c: g[f"basis{c}"] for c in range(4)}
+    nT, stride = int(g["nT"]), int(g["stride"])
+    for proj in ("Galerkin", "LSPG"):
+        res = rom.local_prom_run(X, np.ones(512), [float(g["mu1"]), 5.3], [float(g["mu2"]), 0.017], float(g["At"]), nT,
+                                 g["centers"], bases, g["U_global"], 12, projection=proj)
+        torch.cuda.synchronize()
+        assert rel_l2(res.hist[0].cpu().numpy().T[:, ::stride], g["U_" + proj]) < TOL
+        assert np.array_equal(res.iters[0].cpu().numpy(), g["iters_" + proj])
+    Uo, ito, cl = br.local_prom_burgers(X, float(g["At"]), 60, np.ones(512), 5.3, 0.0, 0.017, g["centers"], bases,
+                                        g["U_global"], 12, projection="LSPG", return_iters=True)
+    assert rel_l2(res.hist[1].cpu().numpy().T[:, :61], Uo) < TOL and np.array_equal(res.iters[1].cpu().numpy()[:60], ito)
+
+    class KM:                                             # what the reference's drivers pass (joblib-loaded KMeans)
+        cluster_centers_ = g["centers"]
+    U = FEMBurgers(X, T).local_prom_burgers(0.05, 10, np.ones(512), float(g["mu1"]), 0.0, float(g["mu2"]), KM(), bases,
+                                            g["U_global"], 12, projection="Galerkin")
+    assert U.shape == (512, 11) and rel_l2(U[:, ::stride], g["U_Galerkin"][:, :3]) < TOL

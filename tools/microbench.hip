@@ -82,6 +82,11 @@ __global__ __launch_bounds__(256, 1) void bench(double* out, long long* cyc, dou
             if (OP == 16) {  // true select between two registers
                 v[j] = sel ? v[j] : w2[j];
             }
+            if (OP == 18) v[j] = v[j] + w2[j];                       // add, register operands
+            if (OP == 19) v[j] = v[j] * w2[j];                       // mul, register operands
+            if (OP == 20) v[j] = __builtin_fma(v[j], 1.0, w2[j]);    // add expressed as fma
+            if (OP == 21) v[j] = __builtin_fma(v[j], w2[j], 0.0);    // mul expressed as fma
+            if (OP == 22) v[j] = __builtin_fma(v[j], w2[j], w2[(j + 1) % UNR]);  // fma, register operands
             if (OP == 17) {  // LDS: one b128 write (2 doubles) + one b128 read at neighbour
                 lds2[lane + 32] = make_double2(v[j], v[j]);
                 double2 a = lds2[lane + 31];
@@ -170,6 +175,11 @@ int main()
     run<15>("2x v_readlane (+xor)", out, cyc, 3);
     run<16>("f64 select (2 cndmask)", out, cyc, 2);
     run<17>("LDS wr b128 + rd b128 + add", out, cyc, 3);
+    run<18>("v_add_f64 reg,reg", out, cyc, 1);
+    run<19>("v_mul_f64 reg,reg", out, cyc, 1);
+    run<20>("fma(x,1.0,y)", out, cyc, 1);
+    run<21>("fma(x,y,0.0)", out, cyc, 1);
+    run<22>("v_fma_f64 reg,reg,reg", out, cyc, 1);
     {
         hipLaunchKernelGGL(chain<0>, dim3(256), dim3(256), 0, 0, out, cyc, 1.5);
         CHECK(hipDeviceSynchronize());
