@@ -42,6 +42,7 @@ class _Common:
     dt: float
     E: float
     mesh_opt: int = 0
+    Un: torch.Tensor = None          # state at the start of the time step (library path only)
 
     def stream(self):
         return _lib.stream_ptr(self.device)
@@ -53,9 +54,9 @@ def _setup(X, u0, mu1, mu2, dt, E, device, max_n=None):
     mesh_opt = _lib.mesh_options(check_mesh(X), supg=False)
     Xd = _as_dev(X, device)
     N = Xd.numel()
-    max_n = L.bg_rom_max_n() if max_n is None else max_n
+    max_n = L.bg_fom_max_n() if max_n is None else max_n
     if N > max_n:
-        raise NotImplementedError(f"ROM kernels cover N <= {max_n} (got {N})")
+        raise NotImplementedError(f"ROM steppers cover N <= {max_n} (got {N})")
     mu1d = _as_dev(mu1, device).reshape(-1)
     mu2d = _as_dev(mu2, device).reshape(-1)
     B = max(mu1d.numel(), mu2d.numel())
@@ -76,6 +77,7 @@ def _setup(X, u0, mu1, mu2, dt, E, device, max_n=None):
 
 
 def _mass_rhs(c, Un, out):
+    c.Un = Un.clone()
     with torch.cuda.device(c.device):
         for b0 in range(0, c.B, 32768):
             b1 = min(c.B, b0 + 32768)
@@ -87,6 +89,8 @@ def _mass_rhs(c, Un, out):
 def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None):
     """Ar, br (and optionally W^T u) of every active sample.  W: (N, r) shared or (B, N, r)."""
     r = W.shape[-1]
+    if r > c.L.bg_rom_max_r() or c.N > c.L.bg_rom_max_n():
+        return _rom_reduce_library(c, W, U, proj, supg, active, Ar, br, wtu)
     stride = 0 if W.dim() == 2 else c.N * r
     with torch.cuda.device(c.device):
         rc = c.L.bg_rom_reduce(c.N, c.B, r, proj, _lib.ptr(c.X), _lib.ptr(W), stride, _lib.ptr(U), _lib.ptr(G),
@@ -96,6 +100,27 @@ def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None):
     if rc == _lib.BG_ERR_UNSUPPORTED_R:
         raise NotImplementedError(f"ROM kernels cover r <= {c.L.bg_rom_max_r()} (got {r})")
     _lib.check(rc, "bg_rom_reduce")
+
+
+def _rom_reduce_library(c, W, U, proj, supg, active, Ar, br, wtu):
+    """Same outputs as bg_rom_reduce for sizes beyond the register-resident MFMA kernels
+    (r > 47 or N > 512): HIP assembly (bg_fom_assemble), then A W, the projection and W^T u as
+    library GEMMs over the batch.  Inactive samples keep their previous outputs."""
+    from . import fom as _fom
+    lo, di, up, rhs = _fom.fom_assemble(c.X.cpu().numpy(), U, c.Un, c.mu1, c.mu2, c.dt, E=c.E, supg=supg,
+                                        device=c.device)
+    Wb = W if W.dim() == 3 else W.unsqueeze(0)
+    z = torch.zeros_like(Wb[:, :1])
+    Y = di.unsqueeze(-1) * Wb + lo.unsqueeze(-1) * torch.cat([z, Wb[:, :-1]], 1) + \
+        up.unsqueeze(-1) * torch.cat([Wb[:, 1:], z], 1)                                   # A W, (B, N, r)
+    L_ = Wb if proj == _lib.BG_PROJ_GALERKIN else Y
+    Ar_new = torch.matmul(L_.transpose(1, 2), Y)
+    br_new = -torch.matmul(L_.transpose(1, 2), rhs.unsqueeze(-1)).squeeze(-1)             # R = -rhs
+    m = torch.ones((c.B,), dtype=torch.bool, device=c.device) if active is None else active.bool()
+    Ar.copy_(torch.where(m[:, None, None], Ar_new, Ar))
+    br.copy_(torch.where(m[:, None], br_new, br))
+    if wtu is not None:
+        wtu.copy_(torch.where(m[:, None], torch.matmul(Wb.transpose(1, 2), U.unsqueeze(-1)).squeeze(-1), wtu))
 
 
 def lu_solve(A, b, sign=1.0, active=None, x=None, info=None):
@@ -159,12 +184,37 @@ class _IterState:
         self.k.zero_()
         self.launched = 0
 
+    def _solve_update_library(self, mode, Ar, br, wtu, q, tol, max_it):
+        """bg_lu_solve_update for n > 64: rocSOLVER LU through torch, same update rules."""
+        act = self.active.bool()
+        try:
+            dq = torch.linalg.solve(Ar, -br)
+        except RuntimeError as e:
+            raise SingularReducedSystem("Singular matrix") from e
+        qn = (wtu if mode == 1 else q) + dq
+        q.copy_(torch.where(act[:, None], qn, q))
+        nd, nq = torch.linalg.vector_norm(dq, dim=1), torch.linalg.vector_norm(qn, dim=1)
+        self.k += self.active
+        if mode == 1:
+            err = nd / nq; more = (err > tol) & (self.k < max_it)
+        elif mode == 2:
+            err = nd / torch.clamp(nq, min=1e-14); more = ~(err < tol) & (self.k < max_it)
+        else:
+            err = nd / (nq + 1e-14); more = (err > tol) & (self.k < max_it)
+        capped = (self.k >= max_it) & (~(err < tol) if mode == 2 else torch.ones_like(more))
+        self.flags |= (act & ~torch.isfinite(err)).to(torch.int32) * _lib.BG_FLAG_NONFINITE
+        self.flags |= (act & capped).to(torch.int32) * _lib.BG_FLAG_HIT_CAP
+        self.active.copy_((act & more).to(torch.int32))
+        return int(self.active.sum().item())
+
     def solve_update(self, mode, Ar, br, wtu, q, tol, max_it):
         """dq = solve(Ar, -br); q, iteration counters and the active mask updated on the device.
         Returns the number of samples that need another iteration (-1: not polled this time)."""
         c = self.c
         self.launched += 1
         self.active_before = self.active.bool()        # samples whose q this call updates
+        if q.shape[1] > 64:
+            return self._solve_update_library(mode, Ar, br, wtu, q, tol, max_it)
         poll = (self.launched >= max_it or self.launched == self.POLL_FIRST or
                 (self.launched > self.POLL_FIRST and (self.launched - self.POLL_FIRST) % self.POLL_EVERY == 0))
         if poll:
@@ -564,9 +614,7 @@ def local_prom_run(X, u0, mu1, mu2, dt, nsteps, centers, local_bases, U_global, 
     c = _setup(X, u0, mu1, mu2, dt, E, device)
     ids = sorted(local_bases.keys())
     widths = [int(np.shape(local_bases[i])[1]) for i in ids]
-    rmax = max(widths)
-    if rmax > c.L.bg_rom_max_r():
-        raise NotImplementedError(f"local bases wider than {c.L.bg_rom_max_r()} modes are not covered")
+    rmax = max(widths)          # beyond 47 modes rom_reduce / solve_update take their library paths
     stack = torch.zeros((len(ids), c.N, rmax), dtype=torch.float64, device=c.device)
     for s_, (i, w_) in enumerate(zip(ids, widths)):
         stack[s_, :, :w_] = _as_dev(local_bases[i], c.device)

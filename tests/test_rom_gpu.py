@@ -340,3 +340,31 @@ def test_local_prom_live_reference(hip):
     U = FEMBurgers(X, T).local_prom_burgers(0.05, 10, np.ones(512), float(g["mu1"]), 0.0, float(g["mu2"]), KM(), bases,
                                             g["U_global"], 12, projection="Galerkin")
     assert U.shape == (512, 11) and rel_l2(U[:, ::stride], g["U_Galerkin"][:, :3]) < TOL
+
+
+def test_library_fallbacks_beyond_kernel_limits(hip):
+    """Sizes the register-resident kernels do not cover still run (HIP assembly + library GEMM / LU):
+    a quadratic manifold on N = 640 > 512, and local POD with 80-mode bases (r > 47, n > 64)."""
+    from burgers_hip import rom
+    rng = np.random.default_rng(17)
+    N, n = 640, 6
+    X, _ = mesh(N)
+    xi = np.linspace(0, 1, N)
+    modes = np.stack([np.ones(N)] + [np.tanh((xi - c0) * 12) for c0 in (0.2, 0.4, 0.6, 0.8)] + [xi], 1)
+    Phi = np.linalg.qr(modes)[0]
+    H = 1e-3 * rng.standard_normal((N, n * (n + 1) // 2))
+    res = rom.quadratic_run(X, np.ones(N), [4.7, 5.2], [0.02, 0.025], 0.04, 6, Phi, H, projection="LSPG")
+    torch.cuda.synchronize()
+    for b, (m1, m2) in enumerate([(4.7, 0.02), (5.2, 0.025)]):
+        U, ito = br.pod_quadratic_manifold(X, 0.04, 6, np.ones(N), m1, 0.0, m2, Phi, H, return_iters=True)
+        assert rel_l2(res.hist[b].cpu().numpy().T, U) < 1e-9 and np.array_equal(res.iters[b].cpu().numpy(), ito)
+    g = load_golden("committed_pod_r96.npz")
+    lp = load_golden("local_pod.npz")
+    X5, _ = mesh(512)
+    bases = {c0: np.ascontiguousarray(g["Phi"][:, :w0]) for c0, w0 in zip(range(4), (80, 72, 66, 80))}
+    res = rom.local_prom_run(X5, np.ones(512), 4.9, 0.022, 0.05, 12, lp["centers"], bases, lp["U_global"], 12,
+                             projection="Galerkin")
+    torch.cuda.synchronize()
+    U, ito, _ = br.local_prom_burgers(X5, 0.05, 12, np.ones(512), 4.9, 0.0, 0.022, lp["centers"], bases, lp["U_global"], 12,
+                                      projection="Galerkin", return_iters=True)
+    assert rel_l2(res.hist[0].cpu().numpy().T, U) < 1e-9 and np.array_equal(res.iters[0].cpu().numpy(), ito)
