@@ -792,6 +792,7 @@ int bg_rom_reduce_lifted(int N, int B, int r, int projection, const double* x, c
                          double* U, const double* G, const double* hfs, const double* mu1, double dt, double E,
                          int supg, const int32_t* active, double* Ar, double* br, double* wtu, void* stream)
 {
+    if (B == 0) return BG_OK;
     if (!q || !U) return BG_ERR_BAD_ARG;
     return rom_reduce_impl(N, B, r, projection, x, Phi, 0, nullptr, G, hfs, mu1, dt, E, supg, active, Ar, br, wtu, q,
                            U, 0, stream);
@@ -800,6 +801,7 @@ int bg_rom_reduce_lifted(int N, int B, int r, int projection, const double* x, c
 int bg_rom_lift(int N, int B, int r, const double* x, const double* Phi, const double* q, const int32_t* active,
                 double* U, void* stream)
 {
+    if (B == 0) return BG_OK;
     if (!q || !U) return BG_ERR_BAD_ARG;
     return rom_reduce_impl(N, B, r, BG_PROJ_GALERKIN, x, Phi, 0, nullptr, nullptr, nullptr, nullptr, 1.0, 0.0, 0,
                            active, nullptr, nullptr, nullptr, q, U, 1, stream);

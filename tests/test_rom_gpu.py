@@ -368,3 +368,24 @@ def test_library_fallbacks_beyond_kernel_limits(hip):
     U, ito, _ = br.local_prom_burgers(X5, 0.05, 12, np.ones(512), 4.9, 0.0, 0.022, lp["centers"], bases, lp["U_global"], 12,
                                       projection="Galerkin", return_iters=True)
     assert rel_l2(res.hist[0].cpu().numpy().T, U) < 1e-9 and np.array_equal(res.iters[0].cpu().numpy(), ito)
+
+
+def test_rom_edge_cases_and_bf16_tier(hip):
+    """Empty batch, zero steps, projection spelling, and the bf16 MLP tier of config 5 (reported, not gated)."""
+    from burgers_hip import rom
+    g = load_golden("committed_pod_r40.npz")
+    X, _ = mesh(512)
+    r = rom.pod_prom_run(X, np.ones(512), np.zeros(0), np.zeros(0), 0.05, 3, g["Phi"], projection="LSPG")
+    assert r.hist.shape == (0, 4, 512) and r.iters.shape == (0, 3)
+    r = rom.pod_prom_run(X, np.ones(512), 4.75, 0.02, 0.05, 0, g["Phi"], projection="Galerkin")
+    assert r.hist.shape == (1, 1, 512) and torch.equal(r.hist[0, 0].cpu(), torch.ones(512, dtype=torch.float64))
+    c = load_golden("committed_quadratic_n21.npz")
+    for spelling in ("lspg", "LSPG", "Lspg", "GALERKIN"):            # case-insensitive in this variant (:1150)
+        rom.quadratic_run(X, np.ones(512), 5.19, 0.026, 0.05, 1, c["Phi"], c["H"], projection=spelling)
+    a = load_golden("ann_n5.npz")
+    model = _ann_model(a)
+    ref = rom.pod_ann_run(X, np.ones(512), 4.56, 0.019, 0.05, 3, a["U_p"], a["U_s"], model)
+    low = rom.pod_ann_run(X, np.ones(512), 4.56, 0.019, 0.05, 3, a["U_p"], a["U_s"], model, ann_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    err = rel_l2(low.hist[0].cpu().numpy(), ref.hist[0].cpu().numpy())
+    assert np.isfinite(low.hist.cpu().numpy()).all() and err < 0.2, err     # bf16 has 8 significant bits
