@@ -18,7 +18,7 @@
  * library against oracle/burgers_ref.py and against the golden fixtures
  * (reference-run vectors and slices of the reference's committed .npy files).
  *
- * Build: see oracle/Makefile  (gcc -O2 -fopenmp -shared -fPIC).
+ * Build: see oracle/Makefile  (gcc -O3 -fopenmp -shared -fPIC; no -march: the .so travels to the GPU box).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -74,14 +74,20 @@ static void forcing(int n, const double *X, double mu2, double *F, double *fs)
     }
 }
 
-/* One sample, whole time loop.  hist is [nsteps+1][n] (time-major). */
+/* One sample, whole time loop.  hist is [nsteps+1][n] (time-major).  Loop-invariant element
+ * constants (h/3, h/6, dt*E/h) are hoisted out of the Picard loop; their values are unchanged. */
 static void fom_one(int n, int nsteps, const double *X, const double *u0, double mu1, double mu2,
                     double dt, double E, double tol, int max_it, int supg,
                     double *hist, int *iters, double *w)
 {
     double *F = w, *fs = w + n, *g = w + 2 * n, *lo = w + 3 * n, *di = w + 4 * n, *up = w + 5 * n,
-           *du2 = w + 6 * n, *r = w + 7 * n, *u = w + 8 * n, *S = w + 9 * n;
+           *du2 = w + 6 * n, *r = w + 7 * n, *u = w + 8 * n, *S = w + 9 * n, *h3 = w + 10 * n,
+           *h6 = w + 11 * n, *eh = w + 12 * n, *hh = w + 13 * n;
     forcing(n, X, mu2, F, fs);
+    for (int e = 0; e < n - 1; ++e) {
+        double h = X[e + 1] - X[e];
+        hh[e] = h; h3[e] = h / 3.0; h6[e] = h / 6.0; eh[e] = dt * E / h;
+    }
     memcpy(hist, u0, sizeof(double) * n);
     for (int s = 0; s < nsteps; ++s) {
         const double *un = hist + (size_t)s * n;
@@ -89,24 +95,25 @@ static void fom_one(int n, int nsteps, const double *X, const double *u0, double
         /* g = M u^n + dt F   (constant over the Picard iterations) */
         for (int i = 0; i < n; ++i) g[i] = 0.0;
         for (int e = 0; e < n - 1; ++e) {
-            double h = X[e + 1] - X[e];
-            g[e]     += h / 6.0 * (2.0 * un[e] + un[e + 1]);
-            g[e + 1] += h / 6.0 * (un[e] + 2.0 * un[e + 1]);
+            g[e]     += h6[e] * (2.0 * un[e] + un[e + 1]);
+            g[e + 1] += h6[e] * (un[e] + 2.0 * un[e + 1]);
         }
         for (int i = 0; i < n; ++i) g[i] += dt * F[i];
         memcpy(u, un, sizeof(double) * n);
         double err = 1.0;
         int k = 0;
         while (err > tol && k < max_it) {
-            for (int i = 0; i < n; ++i) { lo[i] = 0.0; di[i] = 0.0; up[i] = 0.0; S[i] = 0.0; }
+            for (int i = 0; i < n; ++i) { di[i] = 0.0; S[i] = 0.0; }
+            lo[0] = 0.0; up[n - 1] = 0.0;
             for (int e = 0; e < n - 1; ++e) {
-                double h = X[e + 1] - X[e], ul = u[e], ur = u[e + 1];
+                double ul = u[e], ur = u[e + 1];
                 double c1 = (2.0 * ul + ur) / 6.0, c2 = (ul + 2.0 * ur) / 6.0;
-                di[e]     += h / 3.0 - dt * c1 + dt * E / h;
-                up[e]      = h / 6.0 + dt * c1 - dt * E / h;     /* A[e, e+1] */
-                lo[e + 1]  = h / 6.0 - dt * c2 - dt * E / h;     /* A[e+1, e] */
-                di[e + 1] += h / 3.0 + dt * c2 + dt * E / h;
+                di[e]     += h3[e] - dt * c1 + eh[e];
+                up[e]      = h6[e] + dt * c1 - eh[e];     /* A[e, e+1] */
+                lo[e + 1]  = h6[e] - dt * c2 - eh[e];     /* A[e+1, e] */
+                di[e + 1] += h3[e] + dt * c2 + eh[e];
                 if (supg) {
+                    double h = hh[e];
                     double ub = 0.5 * (ul + ur);
                     double vel = fabs(ub) > 1e-10 ? fabs(ub) : 1e-10;
                     double tau = 0.5 * h / (2.0 * vel);
@@ -147,7 +154,7 @@ int bo_fom_run(int n, int B, int nsteps, const double *X, const double *u0, cons
     int fail = 0;
 #pragma omp parallel
     {
-        double *w = (double *)malloc(sizeof(double) * 10 * (size_t)n);
+        double *w = (double *)malloc(sizeof(double) * 14 * (size_t)n);
         if (!w) {
 #pragma omp atomic write
             fail = 1;
