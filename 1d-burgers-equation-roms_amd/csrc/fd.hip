@@ -148,7 +148,7 @@ extern "C" int bg_fd_run(int N, int B, int nsteps, const double* x, const double
     if (N < 3 || B < 0 || nsteps < 0 || max_it < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
     if (B == 0) return BG_OK;
     if (!x || !u0 || !mu1 || !mu2 || !hist || !flags || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
-    if (N > 1024) return BG_ERR_UNSUPPORTED_N;
+    if (N > 2048) return BG_ERR_UNSUPPORTED_N;
     FdArgs a{x, u0, mu1, mu2, hist, iters, flags, dt, tol, N, B, nsteps, max_it};
     const dim3 grid((B + 3) / 4), block(256);
     hipStream_t st = (hipStream_t)stream;
@@ -159,7 +159,9 @@ extern "C" int bg_fd_run(int N, int B, int nsteps, const double* x, const double
     else if (r <= 4) BG_FD(4);
     else if (r <= 8) BG_FD(8);
     else if (r <= 12) BG_FD(12);
-    else BG_FD(16);
+    else if (r <= 16) BG_FD(16);
+    else if (r <= 24) BG_FD(24);
+    else BG_FD(32);
 #undef BG_FD
     return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_LAUNCH;
 }

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
 }
 
 // ---- dispatch ------------------------------------------------------------------------
-constexpr int kRowsPerLane[] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 16};
+constexpr int kRowsPerLane[] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 16, 24, 32};
 
 int rows_per_lane(int N)
 {
@@ -225,6 +225,8 @@ int dispatch_r(int N, F&& f)
         case 10: return f(std::integral_constant<int, 10>{});
         case 12: return f(std::integral_constant<int, 12>{});
         case 16: return f(std::integral_constant<int, 16>{});
+        case 24: return f(std::integral_constant<int, 24>{});
+        case 32: return f(std::integral_constant<int, 32>{});
         default: return BG_ERR_UNSUPPORTED_N;
     }
 }
@@ -237,14 +239,14 @@ int bg_abi_version(void) { return BG_ABI_VERSION; }
 
 int bg_last_hip_error(void) { return g_last_hip_error; }
 
-int bg_fom_max_n(void) { return 64 * 16; }
+int bg_fom_max_n(void) { return 64 * 32; }
 
 const char* bg_strerror(int code)
 {
     switch (code) {
         case BG_OK: return "ok";
         case BG_ERR_BAD_ARG: return "bad argument";
-        case BG_ERR_UNSUPPORTED_N: return "N not supported by the wave-per-sample kernels (2 <= N <= 1024)";
+        case BG_ERR_UNSUPPORTED_N: return "N not supported by the wave-per-sample kernels (2 <= N <= 2048)";
         case BG_ERR_NONUNIFORM: return "mesh is not uniform";
         case BG_ERR_LAUNCH: return "kernel launch failed (see bg_last_hip_error)";
         case BG_ERR_UNSUPPORTED_R: return "reduced dimension not supported";

@@ -54,7 +54,8 @@ const char *bg_strerror(int code);
 /* hipError_t of the most recent failed launch on the calling thread (0 if none). */
 int bg_last_hip_error(void);
 
-/* Largest / smallest N the single-wave FOM kernel handles (rows per lane <= 16). */
+/* Largest N the single-wave FOM / FD kernels handle (rows per lane <= 32, i.e. N <= 2048;
+ * beyond 16 rows per lane part of the state spills to AGPRs / scratch). */
 int bg_fom_max_n(void);
 
 /* ---------------------------------------------------------------------------------
@@ -174,7 +175,7 @@ int bg_lu_solve_update(int n, int B, const double *A, const double *rhs, int mod
  *   reference: FD/fd_burgers.py:59-107 (time + Newton loops), residual :28-35, Jacobian :37-44,
  *   boundary values :19-22 (U[0] = mu1, U[-1] = U[-2]).  Central differences with the lagged
  *   artificial viscosity nu = 0.25 dx max|U|; stop on max|R| < tol or max|dU|/max|U| < tol.
- *   Arrays as in bg_fom_run; x must be the linspace(a, b, N) of the reference; N <= 1024.
+ *   Arrays as in bg_fom_run; x must be the linspace(a, b, N) of the reference; N <= 2048.
  *   iters[b][t] = Newton solves taken in step t; flags: BG_FLAG_HIT_CAP when max_it ran out.
  * ================================================================================= */
 int bg_fd_run(int N, int B, int nsteps, const double *x, const double *u0, const double *mu1,

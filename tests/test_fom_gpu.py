@@ -146,7 +146,7 @@ def test_edge_cases(hip):
     assert r.hist.shape == (1, 1, 256) and torch.equal(r.hist[0, 0].cpu(), torch.ones(256, dtype=torch.float64))
     # N outside the single-wave range and non-uniform meshes are refused, not mis-computed
     with pytest.raises(lib.BurgersHipError):
-        fom.fom_run(np.linspace(0, 100, 1500), np.ones(1500), 4.5, 0.02, 0.05, 1)
+        fom.fom_run(np.linspace(0, 100, 2500), np.ones(2500), 4.5, 0.02, 0.05, 1)
     Xbad = X.copy(); Xbad[7] = Xbad[9]
     with pytest.raises(ValueError):                     # nodes must be strictly increasing
         fom.fom_run(Xbad, np.ones(256), 4.5, 0.02, 0.05, 1)
@@ -239,3 +239,22 @@ def test_fd_newton_stepper(hip):
             assert np.array_equal(res.iters[b].cpu().numpy(), ito), (N, b)
     with pytest.raises(NotImplementedError):
         fd.fom_burgers_newton(0.05, 1, np.ones(512), 4.25, 0.015, use_fd_jacobian=True)
+
+
+@pytest.mark.parametrize("N", [1100, 1536, 2048])
+def test_large_meshes_up_to_2048(hip, N):
+    """24 / 32 rows per lane (part of the state lives in AGPRs / scratch): FEM and FD steppers vs the oracle."""
+    from burgers_hip import fom
+    rng = np.random.default_rng(N)
+    X, _ = mesh(N)
+    B = 4
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    dt = 0.05 * 512 / N
+    h, it, fl = _run(hip, X, np.ones(N), mu1, mu2, dt, 10)
+    ho, ito = bc.fom_run(X, np.ones(N), mu1, mu2, dt, 10)
+    assert rel_l2(h, ho) < TOL and np.array_equal(it, ito)
+    res = fom.fd_run(0.0, 100.0, N, np.ones(N), mu1[:2], mu2[:2], dt, 6)
+    torch.cuda.synchronize()
+    for b in range(2):
+        Uo, ito = br.fd_newton(0.0, 100.0, N, dt, 6, np.ones(N), mu1[b], mu2[b], return_iters=True)
+        assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < TOL and np.array_equal(res.iters[b].cpu().numpy(), ito)
