@@ -379,6 +379,7 @@ def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0,
     Ar, br, _, G = _workspace(c, n)
     st = _IterState(c, n)
     H3t = H3.t().contiguous()
+    Phi_flat = Phid.reshape(1, c.N * n)
     Un = c.u0.clone()
     for m in range(nsteps):
         _mass_rhs(c, Un, G)
@@ -386,7 +387,7 @@ def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0,
         u = decode(q).contiguous()
         st.begin_step()
         while True:
-            T = (Phid.reshape(1, c.N, n) + (q @ H3t).reshape(c.B, c.N, n)).contiguous()
+            T = torch.addmm(Phi_flat, q, H3t).reshape(c.B, c.N, n)    # Phi + H3.q in ONE GEMM (beta*C = Phi)
             rom_reduce(c, T, u, G, proj, False, st.active, Ar, br, None)
             left = st.solve_update(2, Ar, br, None, q, newton_tol, newton_itmax)     # q += dq (:1161-1169)
             u = decode(q).contiguous()                       # inactive samples keep their q, hence their u
