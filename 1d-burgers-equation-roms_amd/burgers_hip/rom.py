@@ -380,6 +380,12 @@ def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0,
     st = _IterState(c, n)
     H3t = H3.t().contiguous()
     Phi_flat = Phid.reshape(1, c.N * n)
+    per = int(c.L.bg_rom_frag_elems(c.N, n))
+    Wf = torch.zeros((c.B, per), dtype=torch.float64, device=c.device) if per > 0 else None
+    if Wf is not None:                                   # zero-padded operands of bg_quad_tangent
+        NP = int(c.L.bg_rom_frag_pad(n))
+        H3p = torch.nn.functional.pad(H3.reshape(c.N, n, n), (0, NP - n)).contiguous()
+        qpad = torch.zeros((c.B, NP), dtype=torch.float64, device=c.device)
     Un = c.u0.clone()
     for m in range(nsteps):
         _mass_rhs(c, Un, G)
@@ -387,8 +393,18 @@ def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0,
         u = decode(q).contiguous()
         st.begin_step()
         while True:
-            T = torch.addmm(Phi_flat, q, H3t).reshape(c.B, c.N, n)    # Phi + H3.q in ONE GEMM (beta*C = Phi)
-            rom_reduce(c, T, u, G, proj, False, st.active, Ar, br, None)
+            if Wf is not None:                               # fused HIP tangent -> fragment-major W -> MFMA reduce
+                qpad[:, :n] = q
+                with torch.cuda.device(c.device):
+                    _lib.check(c.L.bg_quad_tangent(c.N, c.B, n, _lib.ptr(Phid), _lib.ptr(H3p), _lib.ptr(qpad),
+                                                   _lib.ptr(st.active), _lib.ptr(Wf), c.stream()), "bg_quad_tangent")
+                    _lib.check(c.L.bg_rom_reduce_frag(c.N, c.B, n, proj, _lib.ptr(c.X), _lib.ptr(Wf), _lib.ptr(u),
+                                                      _lib.ptr(G), _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, c.mesh_opt,
+                                                      _lib.ptr(st.active), _lib.ptr(Ar), _lib.ptr(br), None, c.stream()),
+                               "bg_rom_reduce_frag")
+            else:                                            # sizes beyond the fused kernels: library GEMM
+                T = torch.addmm(Phi_flat, q, H3t).reshape(c.B, c.N, n)
+                rom_reduce(c, T, u, G, proj, False, st.active, Ar, br, None)
             left = st.solve_update(2, Ar, br, None, q, newton_tol, newton_itmax)     # q += dq (:1161-1169)
             u = decode(q).contiguous()                       # inactive samples keep their q, hence their u
             if left == 0:

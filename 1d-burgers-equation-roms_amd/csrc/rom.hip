@@ -115,6 +115,7 @@ struct ReduceArgs {
     double* Uout;            // [B][N] (only with q_in)
     double dt, E;
     int N, B, r, proj, supg, lift_only, nonuniform;
+    int w_frag;              // 1: W is in the fragment-major layout of bg_quad_tangent (rom_reduce4 only)
 };
 
 template <int S, int NT, int PROJ>
@@ -351,13 +352,28 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
         if (a.active && a.active[smp] == 0) continue;          // workgroup-uniform
         if (a.w_stride != 0 || !have_frags) {
             const double* Wp = a.W + (size_t)smp * (size_t)a.w_stride;
+            if (a.w_frag) {
+                // fragment-major: element (row o*S + s, col 4c + t) at ((c*S + s)*64 + o)*4 + t:
+                // every (c, s) is one coalesced 2 KB read for the workgroup; halos come from owners o -+ 1
 #pragma unroll
-            for (int c = 0; c < NB; ++c) {
-                const int col = 4 * c + t;
+                for (int c = 0; c < NB; ++c) {
 #pragma unroll
-                for (int s = 0; s < S + 2; ++s) {
-                    const int i = rowbase + s - 1;
-                    frag[c][s] = (i >= 0 && i < N && col < r) ? Wp[(size_t)i * r + col] : 0.0;
+                    for (int s = 0; s < S + 2; ++s) {
+                        const int i = rowbase + s - 1;
+                        const int o = (s == 0) ? owner - 1 : ((s == S + 1) ? owner + 1 : owner);
+                        const int ss = (s == 0) ? S - 1 : ((s == S + 1) ? 0 : s - 1);
+                        frag[c][s] = (i >= 0 && i < N) ? Wp[((size_t)(c * S + ss) * 64 + o) * 4 + t] : 0.0;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const int col = 4 * c + t;
+#pragma unroll
+                    for (int s = 0; s < S + 2; ++s) {
+                        const int i = rowbase + s - 1;
+                        frag[c][s] = (i >= 0 && i < N && col < r) ? Wp[(size_t)i * r + col] : 0.0;
+                    }
                 }
             }
             have_frags = true;
@@ -537,6 +553,46 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
 }
 
 // ------------------------------------------------------------------------------------
+// quad_tangent_kernel: T[b] = Phi + H3 . q[b]  (reference tangent(), FEM/fem_burgers.py:1120-1123,
+// with H3[i][a][c] = H[i][pair(a,c)] (1 + delta_ac) folding get_dQ_dq :292-312), written straight
+// into the fragment-major layout rom_reduce4_kernel reads.  Workgroup = one (column block c, row
+// slot s): thread (owner = tid>>2, t = tid&3) keeps its H3 row (n doubles) in registers and walks
+// over the samples; q[b][:] is wave-uniform, so it travels through scalar loads and enters the
+// FMAs as SGPR operands.  Memory-bound on the 8 N n bytes per sample it writes.
+// ------------------------------------------------------------------------------------
+template <int S, int NP>
+__global__ __launch_bounds__(256) void quad_tangent_kernel(const double* __restrict__ Phi, const double* __restrict__ H3p,
+                                                           const double* __restrict__ qp,
+                                                           const int32_t* __restrict__ active, double* __restrict__ Wf,
+                                                           int N, int B, int n, int NB, int chunk)
+{
+    // H3p is [N][n][NP] and qp is [B][NP], both zero-padded in their last dimension: no tail tests
+    const int tid = threadIdx.x, owner = tid >> 2, t = tid & 3;
+    const int c = blockIdx.x / S, s = blockIdx.x % S;
+    const int i = owner * S + s, col = 4 * c + t;
+    const bool live = i < N && col < n;
+    double h[NP];
+    const double* hp = H3p + ((size_t)(live ? i : 0) * n + (live ? col : 0)) * NP;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) h[k] = hp[k];
+    const double phi = live ? Phi[(size_t)i * n + col] : 0.0;
+    const size_t per_sample = (size_t)NB * S * 256;
+    const size_t off = ((size_t)(c * S + s) * 64 + owner) * 4 + t;
+    const int b0 = blockIdx.y * chunk, b1 = min(B, b0 + chunk);
+    for (int b = b0; b < b1; ++b) {
+        if (active && active[b] == 0) continue;            // wave-uniform
+        const double* qb = qp + (size_t)b * NP;            // wave-uniform address: scalar loads
+        double acc0 = phi, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NP; k += 2) {
+            acc0 = __builtin_fma(h[k], qb[k], acc0);
+            acc1 = __builtin_fma(h[k + 1], qb[k + 1], acc1);
+        }
+        Wf[(size_t)b * per_sample + off] = live ? acc0 + acc1 : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // bg_lu_solve: x = solve(A, sign * b), partial pivoting, one wavefront per system.
 //   lane i holds row i of [A | b]; rows are never moved: the pivot of step k is the
 //   not-yet-used lane with the largest |a[k]| (LAPACK gesv's choice up to ties in the
@@ -703,7 +759,7 @@ int bg_rom_max_r(void) { return 47; }
 static int rom_reduce_impl(int N, int B, int r, int projection, const double* x, const double* W, long long w_stride,
                            const double* U, const double* G, const double* hfs, const double* mu1, double dt, double E,
                            int supg, const int32_t* active, double* Ar, double* br, double* wtu, const double* q_in,
-                           double* Uout, int lift_only, void* stream)
+                           double* Uout, int lift_only, void* stream, int w_frag = 0)
 {
     if (N < 2 || B < 0 || r < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
     if (projection != BG_PROJ_GALERKIN && projection != BG_PROJ_LSPG) return BG_ERR_PROJECTION;
@@ -717,7 +773,8 @@ static int rom_reduce_impl(int N, int B, int r, int projection, const double* x,
     a.x = x; a.W = W; a.w_stride = w_stride; a.U = U; a.G = G; a.hfs = hfs; a.mu1 = mu1; a.active = active;
     a.Ar = Ar; a.br = br; a.wtu = wtu; a.dt = dt; a.E = E; a.N = N; a.B = B; a.r = r; a.proj = projection;
     a.supg = supg & BG_OPT_SUPG; a.nonuniform = (supg & BG_OPT_NONUNIFORM) ? 1 : 0;
-    a.q_in = q_in; a.Uout = Uout; a.lift_only = lift_only;
+    a.q_in = q_in; a.Uout = Uout; a.lift_only = lift_only; a.w_frag = w_frag;
+    if (w_frag && (r > 40 || getenv("BG_ROM_FORCE_16X16"))) return BG_ERR_UNSUPPORTED_R;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -796,6 +853,57 @@ int bg_rom_reduce_lifted(int N, int B, int r, int projection, const double* x, c
     if (!q || !U) return BG_ERR_BAD_ARG;
     return rom_reduce_impl(N, B, r, projection, x, Phi, 0, nullptr, G, hfs, mu1, dt, E, supg, active, Ar, br, wtu, q,
                            U, 0, stream);
+}
+
+static int frag_nb(int r) { return r <= 8 ? 2 : (r <= 16 ? 4 : (r <= 24 ? 6 : (r <= 32 ? 8 : 10))); }
+static int frag_s(int N) { return N <= 256 ? 4 : 8; }
+
+int bg_rom_frag_pad(int r) { return (r < 1 || r > 40) ? 0 : 4 * frag_nb(r); }
+
+long long bg_rom_frag_elems(int N, int r)
+{
+    if (N < 2 || N > 512 || r < 1 || r > 40) return 0;
+    return (long long)frag_nb(r) * frag_s(N) * 256;
+}
+
+int bg_quad_tangent(int N, int B, int n, const double* Phi, const double* H3, const double* q,
+                    const int32_t* active, double* Wfrag, void* stream)
+{
+    if (N < 2 || B < 0 || n < 1) return BG_ERR_BAD_ARG;
+    if (N > 512) return BG_ERR_UNSUPPORTED_N;
+    if (n > 40) return BG_ERR_UNSUPPORTED_R;
+    if (B == 0) return BG_OK;
+    if (!Phi || !H3 || !q || !Wfrag) return BG_ERR_BAD_ARG;
+    const int NB = frag_nb(n), S = frag_s(N), NP = 4 * NB;          // NP: padded last dimension of H3p / qp
+    const int chunk = 64;
+    const dim3 grid(NB * S, (B + chunk - 1) / chunk), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define BG_QT(SV, NPV) hipLaunchKernelGGL((quad_tangent_kernel<SV, NPV>), grid, block, 0, st, Phi, H3, q, active, Wfrag, N, B, n, NB, chunk)
+    switch (S * 100 + NP) {
+        case 408: BG_QT(4, 8); break;
+        case 416: BG_QT(4, 16); break;
+        case 424: BG_QT(4, 24); break;
+        case 432: BG_QT(4, 32); break;
+        case 440: BG_QT(4, 40); break;
+        case 808: BG_QT(8, 8); break;
+        case 816: BG_QT(8, 16); break;
+        case 824: BG_QT(8, 24); break;
+        case 832: BG_QT(8, 32); break;
+        case 840: BG_QT(8, 40); break;
+        default: return BG_ERR_UNSUPPORTED_R;
+    }
+#undef BG_QT
+    return check_launch_rom();
+}
+
+int bg_rom_reduce_frag(int N, int B, int r, int projection, const double* x, const double* Wfrag, const double* U,
+                       const double* G, const double* hfs, const double* mu1, double dt, double E, int supg,
+                       const int32_t* active, double* Ar, double* br, double* wtu, void* stream)
+{
+    const long long per = bg_rom_frag_elems(N, r);
+    if (per == 0) return (r > 40) ? BG_ERR_UNSUPPORTED_R : BG_ERR_UNSUPPORTED_N;
+    return rom_reduce_impl(N, B, r, projection, x, Wfrag, per, U, G, hfs, mu1, dt, E, supg, active, Ar, br, wtu,
+                           nullptr, nullptr, 0, stream, 1);
 }
 
 int bg_rom_lift(int N, int B, int r, const double* x, const double* Phi, const double* q, const int32_t* active,

@@ -182,6 +182,24 @@ int bg_fd_run(int N, int B, int nsteps, const double *x, const double *u0, const
               const double *mu2, double dt, double tol, int max_it, double *hist, int32_t *iters,
               int32_t *flags, void *stream);
 
+/* ---------------------------------------------------------------------------------
+ * Quadratic-manifold tangent, fused with the layout the MFMA reduce kernel wants
+ *   reference: tangent(q) = Phi + H @ get_dQ_dq(q)   FEM/fem_burgers.py:1120-1123, :292-312
+ *   H3 [N][n][NP] = H[i][pair(a,c)] * (1 + delta_ac), q [B][NP]: last dimension zero-padded to
+ *                   NP = bg_rom_frag_pad(n) (a multiple of 8; built once / padded on the host side)
+ *   bg_rom_frag_elems(N, r): doubles per sample of the fragment-major layout (0 if N > 512 or r > 40)
+ *   bg_quad_tangent:        Wfrag[b] = Phi + H3 . q[b]   for every active sample
+ *   bg_rom_reduce_frag:     bg_rom_reduce with W given in that layout (stride = bg_rom_frag_elems)
+ * --------------------------------------------------------------------------------- */
+long long bg_rom_frag_elems(int N, int r);
+int bg_rom_frag_pad(int r);
+int bg_quad_tangent(int N, int B, int n, const double *Phi, const double *H3, const double *q,
+                    const int32_t *active, double *Wfrag, void *stream);
+int bg_rom_reduce_frag(int N, int B, int r, int projection, const double *x, const double *Wfrag,
+                       const double *U, const double *G, const double *hfs, const double *mu1, double dt,
+                       double E, int supg, const int32_t *active, double *Ar, double *br, double *wtu,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif
