@@ -21,6 +21,8 @@ namespace {
 
 using namespace bg;
 using f64x4 = __attribute__((ext_vector_type(4))) double;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 int check_launch_rom()
 {
@@ -333,7 +335,13 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
     constexpr int NPAIR = Pairs4<NB, PROJ, WTU>::total;
     constexpr int RW = 4 * NB;                   // padded reduced dimension
     constexpr bool GAL = PROJ == BG_PROJ_GALERKIN;
-    __shared__ double s_u[NPAD + 2];
+    // u, G, hfs of the current sample; double-buffered so that the NEXT sample's rows can stream in
+    // with global_load_lds (no VGPRs, no wait) while this sample's MFMAs run.  u sits at offset 2
+    // (16-byte aligned for the LDS DMA) with one zero halo entry on each side.
+    __shared__ __attribute__((aligned(16))) double s_u[2][NPAD + 4];
+    __shared__ __attribute__((aligned(16))) double s_g[2][NPAD];
+    __shared__ __attribute__((aligned(16))) double s_h[2][NPAD];
+    __shared__ __attribute__((aligned(16))) double s_qp[2][RW + 24];   // prefetched q (lifted mode), dword DMA
     __shared__ double s_coef[NPAD][4];
     __shared__ double s_red[5][RW][RW + 4];      // per-wave  Ar | [br, W^T u (Galerkin), 0, 0]; [4] = dump for idle lanes
     __shared__ double s_wtu[5][RW];              // per-wave  W^T u (LSPG); [4] = dump
@@ -348,8 +356,39 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
     double frag[NB][S + 2];                      // W[rowbase + s - 1][4 c + t]
     bool have_frags = false;
 
-    for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
-        if (a.active && a.active[smp] == 0) continue;          // workgroup-uniform
+    for (int i = tid; i < 2 * (NPAD + 4); i += 256) (&s_u[0][0])[i] = 0.0;   // halos and padded rows stay finite
+    for (int i = tid; i < 2 * NPAD; i += 256) { (&s_g[0][0])[i] = 0.0; (&s_h[0][0])[i] = 0.0; }
+    __syncthreads();
+    // LDS DMA needs 16-byte aligned, fully in-range source chunks: even N (row starts stay aligned)
+    const bool pref = (N % 2 == 0) && !a.lift_only;
+    auto next_active = [&](int from) {
+        int n2 = from;
+        while (n2 < a.B && a.active && a.active[n2] == 0) n2 += gridDim.x;
+        return n2;
+    };
+    auto prefetch = [&](int smp_n, int buf_n) {
+        const int idx = w * 128 + lane * 2;              // each wave streams 1 KiB per array
+        if (idx < NPAD && idx + 1 < N) {
+            const size_t o = (size_t)smp_n * N + idx;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a.G + o), (lds_void_t*)(&s_g[buf_n][w * 128]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(a.hfs + o), (lds_void_t*)(&s_h[buf_n][w * 128]), 16, 0, 0);
+            if (!a.q_in)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(a.U + o), (lds_void_t*)(&s_u[buf_n][2 + w * 128]), 16, 0, 0);
+        }
+        if (a.q_in && w == 0) {                              // q[smp_n][0..r): 2r dwords, 64 per instruction
+            const float* qsrc = reinterpret_cast<const float*>(a.q_in + (size_t)smp_n * r);
+            if (lane < 2 * r)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(qsrc + lane), (lds_void_t*)(&s_qp[buf_n][0]), 4, 0, 0);
+            if (lane + 64 < 2 * r)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(qsrc + 64 + lane), (lds_void_t*)(&s_qp[buf_n][32]), 4, 0, 0);
+        }
+    };
+    int smp = next_active(blockIdx.x);
+    int buf = 0;
+    if (pref && smp < a.B) prefetch(smp, 0);
+
+    while (smp < a.B) {
+        const int nxt = next_active(smp + gridDim.x);
         if (a.w_stride != 0 || !have_frags) {
             const double* Wp = a.W + (size_t)smp * (size_t)a.w_stride;
             if (a.w_frag) {
@@ -381,12 +420,15 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
         // ---- stage u (from HBM, or lifted u = W q from the register-resident basis) ----------
         if (a.q_in) {
             double qv[NB];
+            if (pref) {                                          // q arrived by LDS DMA one sample ago
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 const int col = 4 * c + t;
-                qv[c] = col < r ? a.q_in[(size_t)smp * r + col] : 0.0;
+                qv[c] = col < r ? (pref ? s_qp[buf][col] : a.q_in[(size_t)smp * r + col]) : 0.0;
             }
-            if (tid == 0) { s_u[0] = 0.0; s_u[NPAD + 1] = 0.0; }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 double p = 0.0;
@@ -396,26 +438,24 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
                 p += dpp_mov<0x4E>(p);             // quad_perm [2,3,0,1]
                 if (t == 0) {
                     const int i = rowbase + s;
-                    s_u[i + 1] = p;
+                    s_u[buf][i + 2] = (i < N) ? p : 0.0;
                     if (i < N) a.Uout[(size_t)smp * N + i] = p;
                 }
             }
-        } else {
+        } else if (!pref) {
             const double* up_ = a.U + (size_t)smp * N;
-            for (int i = tid; i < NPAD + 2; i += 256) {
-                const int gi = i - 1;
-                s_u[i] = (gi >= 0 && gi < N) ? up_[gi] : 0.0;
-            }
+            for (int i = tid; i < NPAD; i += 256) s_u[buf][i + 2] = (i < N) ? up_[i] : 0.0;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this sample's LDS DMA has landed (every wave waits for its own)
         __syncthreads();
-        if (a.lift_only) continue;                               // workgroup-uniform
+        if (a.lift_only) { smp = nxt; continue; }                // workgroup-uniform
         // ---- assembly into LDS (same arithmetic as rom_reduce_kernel) -----------------------
         const double mu1 = a.mu1[smp];
         for (int i = tid; i < NPAD; i += 256) {
             double lo = 0.0, di = 1.0, up = 0.0, rhs = 0.0;
             if (i < N) {
-                const double um = s_u[i], u0 = s_u[i + 1], ur = s_u[i + 2];
-                const double gi = a.G[(size_t)smp * N + i];
+                const double um = s_u[buf][i + 1], u0 = s_u[buf][i + 2], ur = (i + 1 < N) ? s_u[buf][i + 3] : 0.0;
+                const double gi = pref ? s_g[buf][i] : a.G[(size_t)smp * N + i];
                 double aoffL = mc.aoff, aoffR = mc.aoff, ddL = mc.dd1, ddR = mc.dd1;
                 if (a.nonuniform && i > 0) {
                     const double hl = a.x[i] - a.x[i - 1];
@@ -430,14 +470,14 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
                 } else {
                     const double wl = um + u0;
                     lo = __builtin_fma(-mc.dt6, wl + u0, aoffL);
-                    const double tl = __builtin_fma(wl, u0 - um, -a.hfs[(size_t)smp * N + i - 1]);
+                    const double tl = __builtin_fma(wl, u0 - um, -(pref ? s_h[buf][i - 1] : a.hfs[(size_t)smp * N + i - 1]));
                     const double sl = tl * rcp(fmax(fabs(wl), 2.0e-10));
                     double b = __builtin_fma(-mc.kap, sl, gi);
                     if (i < N - 1) {
                         const double wr = u0 + ur;
                         up = __builtin_fma(mc.dt6, wr + u0, aoffR);
                         di = __builtin_fma(mc.dt6, um - ur, ddL + ddR);
-                        const double tr = __builtin_fma(wr, ur - u0, -a.hfs[(size_t)smp * N + i]);
+                        const double tr = __builtin_fma(wr, ur - u0, -(pref ? s_h[buf][i] : a.hfs[(size_t)smp * N + i]));
                         const double sr = tr * rcp(fmax(fabs(wr), 2.0e-10));
                         b = __builtin_fma(mc.kap, sr, b);
                     } else {
@@ -451,6 +491,7 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
             s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = -rhs;   // [3] = R
         }
         __syncthreads();
+        if (pref && nxt < a.B) prefetch(nxt, buf ^ 1);           // streams in under the MFMA phase
         // ---- MFMA contraction: every step feeds 16 mesh rows per wave ---------------------------
         double acc[NPAIR];
 #pragma unroll
@@ -459,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
         for (int s = 0; s < S; ++s) {
             const int i = rowbase + s;
             const double lo = s_coef[i][0], di = s_coef[i][1], up = s_coef[i][2], R = s_coef[i][3];
-            const double ui = s_u[i + 1];
+            const double ui = s_u[buf][i + 2];
             double Y[NB];
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
@@ -549,6 +590,8 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
             }
         }
         __syncthreads();
+        smp = nxt;
+        buf ^= 1;
     }
 }
 
