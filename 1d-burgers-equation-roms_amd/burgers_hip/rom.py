@@ -495,6 +495,43 @@ class AnnEvaluator:
                 return _mlp_forward_jacobian(self.layers, x)[1].to(torch.float64)
             return ann_jacobian(self.model, x).to(torch.float64)
 
+    # ---- hipGraph replay: the MLP is ~25 tiny launches per evaluation, launch-bound at ROM batch sizes;
+    # both evaluations are captured once per batch shape and replayed from static buffers.
+    def capture(self, B, n, device):
+        self._graphs = None
+        if device.type != "cuda":
+            return
+        try:
+            q_in = torch.zeros((B, n), dtype=torch.float64, device=device)
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):                      # warm-up outside capture (lazy inits, autotune)
+                for _ in range(2):
+                    self.jacobian(q_in); self.forward(q_in)
+            torch.cuda.current_stream(device).wait_stream(side)
+            gj, gf = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gj):
+                j_out = self.jacobian(q_in)
+            with torch.cuda.graph(gf):
+                f_out = self.forward(q_in)
+            self._graphs = (q_in, gj, j_out, gf, f_out)
+        except Exception:                                      # capture is an optimisation only
+            self._graphs = None
+
+    def jacobian_replay(self, q):
+        if getattr(self, "_graphs", None) is None:
+            return self.jacobian(q)
+        q_in, gj, j_out, _, _ = self._graphs
+        q_in.copy_(q); gj.replay()
+        return j_out
+
+    def forward_replay(self, q):
+        if getattr(self, "_graphs", None) is None:
+            return self.forward(q)
+        q_in, _, _, gf, f_out = self._graphs
+        q_in.copy_(q); gf.replay()
+        return f_out
+
 
 def ann_jacobian(model, q32):
     """Batched input-Jacobian (B, nbar, n) of ``model`` in fp32; forward mode, since n << nbar.
@@ -517,6 +554,7 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
     UpT, UsT = Up.t().contiguous(), Us.t().contiguous()
     model = model.to(device=c.device, dtype=ann_dtype).eval()
     ann = AnnEvaluator(model, n, ann_dtype)
+    ann.capture(c.B, n, c.device)
     hist, iters, flags = _alloc_hist(c, nsteps)
     Ar, br, _, G = _workspace(c, n)
     st = _IterState(c, n)
@@ -526,11 +564,11 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
         qp = (U0 @ Up).contiguous()                                         # (:1197)
         st.begin_step()
         while True:
-            dN = ann.jacobian(qp)                                           # (B, nbar, n), fp32 like :1219
+            dN = ann.jacobian_replay(qp)                                    # (B, nbar, n), fp32 like :1219
             dD = (Up.unsqueeze(0) + torch.matmul(Us, dN)).contiguous()      # U_p + U_s dN        (:1224)
             rom_reduce(c, dD, U0, G, proj, True, st.active, Ar, br, None)
             left = st.solve_update(3, Ar, br, None, qp, tol, max_it)        # q_p += dq           (:1237-1244)
-            qs = ann.forward(qp)                                            # (:1241)
+            qs = ann.forward_replay(qp)                                     # (:1241)
             U0 = (qp @ UpT + qs @ UsT).contiguous()                         # (:1242)
             if left == 0:
                 break
