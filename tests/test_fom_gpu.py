@@ -258,3 +258,33 @@ def test_large_meshes_up_to_2048(hip, N):
     for b in range(2):
         Uo, ito = br.fd_newton(0.0, 100.0, N, dt, 6, np.ones(N), mu1[b], mu2[b], return_iters=True)
         assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < TOL and np.array_equal(res.iters[b].cpu().numpy(), ito)
+
+
+@pytest.mark.parametrize("N", [2, 3, 5, 63, 64, 65, 127, 129])
+def test_tiny_and_boundary_mesh_sizes(hip, N):
+    """Smallest meshes and sizes around the rows-per-lane switch points (1 row per lane and its neighbours)."""
+    rng = np.random.default_rng(1000 + N)
+    X, _ = mesh(N)
+    B = 5
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    dt = min(0.5, 0.05 * 512 / N)
+    h, it, fl = _run(hip, X, np.ones(N), mu1, mu2, dt, 8, E=0.01)
+    ho, ito = bc.fom_run(X, np.ones(N), mu1, mu2, dt, 8, E=0.01)
+    assert np.isfinite(ho).all()
+    assert rel_l2(h, ho) < TOL and np.array_equal(it, ito)
+
+
+def test_nonfinite_state_exits_like_the_reference(hip):
+    """The reference's loop test `error_U > 1e-6` is False for NaN, so a non-finite state leaves the Picard
+    loop after one pass per step, silently.  Same exit here (identical iteration counts), plus the
+    NONFINITE flag the reference does not have."""
+    from burgers_hip import fom, lib
+    X, _ = mesh(256)
+    u0 = np.ones((2, 256)); u0[1, 40] = np.nan
+    r = fom.fom_run(X, u0, [5.0, 5.0], [0.02, 0.02], 0.05, 6)
+    torch.cuda.synchronize()
+    ho, ito = bc.fom_run(X, u0, [5.0, 5.0], [0.02, 0.02], 0.05, 6)
+    it = r.iters.cpu().numpy(); fl = r.flags.cpu().numpy()
+    assert np.array_equal(it, ito) and (it[1] == 1).all()
+    assert fl[1] & lib.BG_FLAG_NONFINITE and not (fl[0] & lib.BG_FLAG_NONFINITE)
+    assert rel_l2(r.hist[0].cpu().numpy(), ho[0]) < TOL          # the healthy neighbour is untouched
