@@ -144,6 +144,27 @@ def stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+PINNED_MIN_BYTES = 1 << 20
+
+
+def to_host(t):
+    """Device tensor -> numpy array.  Results of a sweep are gigabytes, and a copy into fresh
+    pageable memory runs far below the PCIe rate, so anything over 1 MiB goes through torch's
+    caching pinned-host allocator: the returned ndarray is a view of the pinned block, which
+    returns to that cache when the array is dropped.  BG_PINNED_RESULTS=0 keeps pageable memory."""
+    t = t.detach()
+    if (t.is_cuda and t.numel() * t.element_size() >= PINNED_MIN_BYTES
+            and os.environ.get("BG_PINNED_RESULTS", "1") != "0"):
+        try:
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        except RuntimeError:            # pinning refused (ulimit, fragmentation): pageable copy
+            return t.cpu().numpy()
+        host.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return host.numpy()
+    return t.cpu().numpy()
+
+
 def mesh_options(X, supg=True):
     """Option bits for the assembly-carrying entry points: SUPG on/off, uniform/non-uniform mesh."""
     return (BG_OPT_SUPG if supg else 0) | (0 if mesh_is_uniform(X) else BG_OPT_NONUNIFORM)

@@ -17,6 +17,7 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
 from burgers_hip import fom as _fom          # noqa: E402
+from burgers_hip import lib as _lib          # noqa: E402
 
 __all__ = ["FDBurgers"]
 
@@ -39,7 +40,7 @@ class FDBurgers:
         batched = np.ndim(mu1) > 0 or np.ndim(mu2) > 0
         res = _fom.fd_run(self.a, self.b, self.N, np.asarray(U0, dtype=np.float64), mu1, mu2, dt, int(n_steps),
                           max_iter=max_iter, tol=tol)
-        U = res.snapshots().cpu().numpy()
+        U = _lib.to_host(res.snapshots())
         self.last_iters = res.iters.cpu().numpy()
         self.last_flags = res.flags.cpu().numpy()
         if not batched:

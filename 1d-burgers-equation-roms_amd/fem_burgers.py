@@ -65,7 +65,7 @@ class FEMBurgers:
         snaps = res.snapshots()                       # (B, N, nT+1) on device
         self.last_iters = res.iters.cpu().numpy()
         self.last_flags = res.flags.cpu().numpy()
-        U = snaps.cpu().numpy()
+        U = _lib.to_host(snaps)
         if self.verbose:
             for b in range(U.shape[0]):
                 for n, k in enumerate(self.last_iters[b]):

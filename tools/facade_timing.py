@@ -12,9 +12,15 @@ rng = np.random.default_rng(20251121)
 mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
 fem = FEMBurgers(X, T)
 fem.fom_burgers(dt, 5, np.ones(N), mu1[:8], 0.0, mu2[:8])
+for label in ("first call (pins the host block)", "steady state (cached pinned block)", "steady state"):
+    t0 = time.perf_counter(); U = fem.fom_burgers(dt, nT, np.ones(N), mu1, 0.0, mu2); t = time.perf_counter() - t0
+    steps = int(fem.last_iters.sum())
+    print(f"facade, {label}: host ndarray out, {U.nbytes/1e9:.2f} GB over PCIe: {t*1e3:.1f} ms -> {steps/t:.3e} sample-Newton-steps/s")
+    chk = float(U[3, 5, -1]); del U
+os.environ["BG_PINNED_RESULTS"] = "0"
 t0 = time.perf_counter(); U = fem.fom_burgers(dt, nT, np.ones(N), mu1, 0.0, mu2); t = time.perf_counter() - t0
-steps = int(fem.last_iters.sum())
-print(f"facade (host ndarray out, {U.nbytes/1e9:.2f} GB over PCIe): {t*1e3:.1f} ms -> {steps/t:.3e} sample-Newton-steps/s")
+print(f"facade, pageable (BG_PINNED_RESULTS=0): {t*1e3:.1f} ms -> {steps/t:.3e}; same value: {float(U[3, 5, -1]) == chk}")
+del U
 res = fom.fom_run(X, np.ones(N), mu1, mu2, dt, nT); torch.cuda.synchronize()
 t0 = time.perf_counter(); res = fom.fom_run(X, np.ones(N), mu1, mu2, dt, nT); torch.cuda.synchronize(); t = time.perf_counter() - t0
 print(f"device-resident fom_run: {t*1e3:.1f} ms -> {steps/t:.3e}")
