@@ -32,6 +32,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np
 import torch
 
+FP64_VALU_PEAK_TF = 78.6       # MI355X_MICROARCH.md: fp64 vector peak (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
+# fp64 flop per lane and Picard iteration of fom_fused_kernel<16> read off the ISA (tools/asm_stats.py):
+# 384 FMA (2 flop) + 211 mul/add + 16 max + 38 rcp = 1033; x 64 lanes / 1024 rows = 64.6 flop per mesh row
+FLOP_PER_ROW_STEP = 1033 * 64 / 1024.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SEED = 20251121
 
@@ -187,7 +191,12 @@ def main():
                          "kernel": "fom_fused_kernel", "kernel_ms_avg": float(np.mean(kernel_ms)),
                          "algorithmic_bytes_per_launch": steps_per_pass * alg_bytes_per_step,
                          "note": "algorithmic bytes = 24*N per sample-Newton-step (streaming model); the fused kernel keeps the "
-                                 "state in registers, so real HBM traffic is far lower and frac may exceed 1"},
+                                 "state in registers, so real HBM traffic is far lower and frac may exceed 1; the binding "
+                                 "resource is fp64 VALU issue, priced in fp64_valu",
+                         "fp64_valu": {"achieved": steps_per_pass * FLOP_PER_ROW_STEP * args.n / avg_kernel_s / 1e12,
+                                       "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                                       "frac": steps_per_pass * FLOP_PER_ROW_STEP * args.n / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TF,
+                                       "flop_per_row_step": FLOP_PER_ROW_STEP}},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, mu1, mu2)

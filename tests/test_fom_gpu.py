@@ -288,3 +288,32 @@ def test_nonfinite_state_exits_like_the_reference(hip):
     assert np.array_equal(it, ito) and (it[1] == 1).all()
     assert fl[1] & lib.BG_FLAG_NONFINITE and not (fl[0] & lib.BG_FLAG_NONFINITE)
     assert rel_l2(r.hist[0].cpu().numpy(), ho[0]) < TOL          # the healthy neighbour is untouched
+
+
+def test_randomised_differential_sweep(hip):
+    """Seeded random cases over the whole supported size range (every rows-per-lane instantiation,
+    uniform and graded meshes, with and without diffusion, non-constant initial states, odd batch
+    sizes) against the C oracle: rel-L2 <= 1e-10 and identical iteration counts."""
+    rng = np.random.default_rng(4242)
+    sizes = [int(n) for n in rng.integers(2, 2049, 22)] + [640, 641, 768, 1025, 1537]
+    worst = 0.0
+    for case, N in enumerate(sizes):
+        B = int(rng.integers(1, 8))
+        nsteps = int(rng.integers(3, 9))
+        X = np.linspace(0.0, 100.0, N)
+        if case % 3 == 1 and N > 3:                      # graded mesh, strictly increasing
+            w = rng.uniform(0.6, 1.4, N - 1)
+            X = np.concatenate([[0.0], np.cumsum(w)]) * (100.0 / w.sum())
+        E = [0.0, 0.003, 0.02][case % 3]
+        h = 100.0 / (N - 1)
+        dt = float(min(0.4, rng.uniform(0.08, 0.2) * h))  # CFL <= 1.1 at mu1 <= 5.5: the Picard loop converges
+        mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+        u0 = 1.0 + 0.1 * np.sin(np.outer(rng.uniform(0.02, 0.1, B), X)) * np.exp(-X / 60.0)
+        hh, it, fl = _run(hip, X, u0, mu1, mu2, dt, nsteps, E=E)
+        ho, ito = bc.fom_run(X, u0, mu1, mu2, dt, nsteps, E=E)
+        assert np.isfinite(ho).all() and ito.max() < 20, f"case {case} N={N} left the convergent regime"
+        e = rel_l2(hh, ho)
+        worst = max(worst, e)
+        assert e < TOL and np.array_equal(it, ito), f"case {case}: N={N} B={B} E={E} dt={dt:.4f} rel={e:.2e}"
+        assert (fl == 0).all()
+    assert worst < TOL

@@ -389,3 +389,42 @@ def test_rom_edge_cases_and_bf16_tier(hip):
     torch.cuda.synchronize()
     err = rel_l2(low.hist[0].cpu().numpy(), ref.hist[0].cpu().numpy())
     assert np.isfinite(low.hist.cpu().numpy()).all() and err < 0.2, err     # bf16 has 8 significant bits
+
+
+def test_rom_reduce_randomised_sizes(hip):
+    """Seeded random (N, r) over the fused kernels' whole range -- every column-block count of the
+    4x4x4 kernel, the 16x16x4 kernel above r = 40, odd N (no LDS-DMA prefetch), tiny meshes --
+    shared and per-sample bases, both projections, against the oracle."""
+    from burgers_hip import rom
+    rng = np.random.default_rng(777)
+    cases = [(int(rng.integers(2, 513)), int(rng.integers(1, 48))) for _ in range(14)]
+    cases += [(2, 1), (3, 2), (511, 40), (512, 41), (257, 24), (64, 47)]
+    for N, r in cases:
+        X, _ = mesh(N)
+        B = int(rng.integers(1, 6))
+        mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+        dt, E = 0.04, 0.005
+        U = 1.0 + 4.0 * rng.random((B, N)); Un = 1.0 + 4.0 * rng.random((B, N))
+        shared = bool(rng.integers(0, 2))
+        W = rng.standard_normal((N, r)) if shared else rng.standard_normal((B, N, r))
+        c = rom._setup(X, Un, mu1, mu2, dt, E, None)
+        G = torch.empty((B, N), dtype=torch.float64, device="cuda")
+        rom._mass_rhs(c, _dev(Un), G)
+        M3, K3 = br.mass_tridiag(X), br.diffusion_tridiag(X)
+        for pname, proj in (("galerkin", 0), ("lspg", 1)):
+            Ar = torch.zeros((B, r, r), dtype=torch.float64, device="cuda")
+            brr = torch.zeros((B, r), dtype=torch.float64, device="cuda")
+            wtu = torch.zeros((B, r), dtype=torch.float64, device="cuda")
+            rom.rom_reduce(c, _dev(W), _dev(U), G, proj, True, None, Ar, brr, wtu)
+            torch.cuda.synchronize()
+            Ar, brr, wtu = Ar.cpu().numpy(), brr.cpu().numpy(), wtu.cpu().numpy()
+            for b in range(B):
+                Wb = W if shared else W[b]
+                lo, di, up = br.system_tridiag(M3, K3, br.convection_tridiag(X, U[b]), dt, E)
+                bb = br.tridiag_matvec(*M3, Un[b]) + dt * br.forcing_vector(X, mu2[b]) - dt * br.supg_term(X, U[b], mu2[b])
+                bb[0] = mu1[b]
+                R = br.tridiag_matvec(lo, di, up, U[b]) - bb
+                Ar_ref, br_ref = br._reduce(lo, di, up, R, Wb, pname)
+                assert rel_l2(Ar[b], Ar_ref) < 1e-13, (N, r, pname, shared, b)
+                assert rel_l2(brr[b], br_ref) < 1e-12, (N, r, pname, shared, b)
+                assert rel_l2(wtu[b], Wb.T @ U[b]) < 1e-13
