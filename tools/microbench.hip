@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256, 1) void bench(double* out, long long* cyc, dou
     double* lds = lds_all[threadIdx.x >> 6];
     double2* lds2 = lds2_all[threadIdx.x >> 6];
     const bool sel = (lane * 2654435761u) & 64;
+    const int dynlane = __builtin_amdgcn_readfirstlane((int)(seed * 4.0) + (int)(blockIdx.x & 7));   // wave-uniform, not a constant
     double w2[UNR];
 #pragma unroll
     for (int j = 0; j < UNR; ++j) w2[j] = seed * 1.5 + j;
@@ -87,6 +88,42 @@ __global__ __launch_bounds__(256, 1) void bench(double* out, long long* cyc, dou
             if (OP == 20) v[j] = __builtin_fma(v[j], 1.0, w2[j]);    // add expressed as fma
             if (OP == 21) v[j] = __builtin_fma(v[j], w2[j], 0.0);    // mul expressed as fma
             if (OP == 22) v[j] = __builtin_fma(v[j], w2[j], w2[(j + 1) % UNR]);  // fma, register operands
+            if (OP == 23 || OP == 24) {  // LU-style staged broadcast: 8 readlanes (dynamic / first lane), then 4 FMAs
+                if ((j & 3) == 0) {
+                    double pv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int lo, hi;
+                        if (OP == 23) {
+                            lo = __builtin_amdgcn_readlane(__double2loint(v[j + u]), dynlane);
+                            hi = __builtin_amdgcn_readlane(__double2hiint(v[j + u]), dynlane);
+                        } else {
+                            lo = __builtin_amdgcn_readfirstlane(__double2loint(v[j + u]));
+                            hi = __builtin_amdgcn_readfirstlane(__double2hiint(v[j + u]));
+                        }
+                        pv[u] = __hiloint2double(hi, lo);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[j + u] = __builtin_fma(w2[j + u], pv[u], v[j + u] * 0.5);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (OP == 25) {  // LDS broadcast: every lane reads the same 16 bytes, 2 FMAs consume them
+                if ((j & 1) == 0) {
+                    double2 a = lds2[(it + j) & 127];
+                    v[j] = __builtin_fma(w2[j], a.x, v[j] * 0.5);
+                    v[j + 1] = __builtin_fma(w2[j + 1], a.y, v[j + 1] * 0.5);
+                }
+            }
+            if (OP == 26) {  // one lane publishes 2 doubles, all lanes read them back (pivot-row round trip)
+                if ((j & 1) == 0) {
+                    if (lane == dynlane) lds2[j] = make_double2(v[j], v[j + 1]);
+                    double2 a = lds2[j];
+                    v[j] = __builtin_fma(w2[j], a.x, v[j] * 0.5);
+                    v[j + 1] = __builtin_fma(w2[j + 1], a.y, v[j + 1] * 0.5);
+                }
+            }
             if (OP == 17) {  // LDS: one b128 write (2 doubles) + one b128 read at neighbour
                 lds2[lane + 32] = make_double2(v[j], v[j]);
                 double2 a = lds2[lane + 31];
@@ -137,25 +174,25 @@ __global__ void rcp_accuracy(const double* x, double* r0, double* r1, double* r2
 }
 
 template <int OP>
-int run(const char* name, double* out, long long* cyc, int per_iter_instr)
+int run(const char* name, double* out, long long* cyc, int per_iter_instr, int grid = 256)
 {
-    hipLaunchKernelGGL(bench<OP>, dim3(256), dim3(256), 0, 0, out, cyc, 1.5);
+    hipLaunchKernelGGL(bench<OP>, dim3(grid), dim3(256), 0, 0, out, cyc, 1.5);
     CHECK(hipDeviceSynchronize());
-    hipLaunchKernelGGL(bench<OP>, dim3(256), dim3(256), 0, 0, out, cyc, 1.5);
+    hipLaunchKernelGGL(bench<OP>, dim3(grid), dim3(256), 0, 0, out, cyc, 1.5);
     CHECK(hipDeviceSynchronize());
-    std::vector<long long> h(256);
-    CHECK(hipMemcpy(h.data(), cyc, 256 * sizeof(long long), hipMemcpyDeviceToHost));
-    double avg = 0; for (auto c : h) avg += c; avg /= 256;
-    printf("%-28s %8.2f cycles per op-group (%d instr each) -> %.2f cyc/instr\n", name, avg / (ITER * UNR), per_iter_instr,
-           avg / (ITER * UNR) / per_iter_instr);
+    std::vector<long long> h(grid);
+    CHECK(hipMemcpy(h.data(), cyc, grid * sizeof(long long), hipMemcpyDeviceToHost));
+    double avg = 0; for (auto c : h) avg += c; avg /= grid;
+    printf("%-28s %8.2f cycles per op-group (%d instr each) -> %.2f cyc/instr  [%d waves/SIMD]\n", name, avg / (ITER * UNR),
+           per_iter_instr, avg / (ITER * UNR) / per_iter_instr, grid / 256);
     return 0;
 }
 
 int main()
 {
     double* out; long long* cyc;
-    CHECK(hipMalloc(&out, 256 * 256 * sizeof(double)));
-    CHECK(hipMalloc(&cyc, 256 * sizeof(long long)));
+    CHECK(hipMalloc(&out, 1024 * 256 * sizeof(double)));
+    CHECK(hipMalloc(&cyc, 1024 * sizeof(long long)));
     printf("grid 256 WG x 256 threads (1 wave/SIMD on every CU), s_memtime-class counter (100 MHz?) see scale below\n");
     run<0>("v_fma_f64", out, cyc, 1);
     run<1>("v_mul_f64", out, cyc, 1);
@@ -180,6 +217,14 @@ int main()
     run<20>("fma(x,1.0,y)", out, cyc, 1);
     run<21>("fma(x,y,0.0)", out, cyc, 1);
     run<22>("v_fma_f64 reg,reg,reg", out, cyc, 1);
+    // LU broadcast candidates; per op-group = one matrix column (UNR columns per pass)
+    for (int g : {256, 1024}) {
+        run<22>("fma reg,reg,reg", out, cyc, 1, g);
+        run<23>("col: 2 readlane(dyn)+mul+fma", out, cyc, 4, g);
+        run<24>("col: 2 readfirstlane+mul+fma", out, cyc, 4, g);
+        run<25>("col: 1/2 ds_read_b128 bcast+mul+fma", out, cyc, 3, g);
+        run<26>("col: 1/2 (1-lane wr + rd b128)+mul+fma", out, cyc, 3, g);
+    }
     {
         hipLaunchKernelGGL(chain<0>, dim3(256), dim3(256), 0, 0, out, cyc, 1.5);
         CHECK(hipDeviceSynchronize());
