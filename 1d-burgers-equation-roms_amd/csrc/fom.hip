@@ -10,6 +10,7 @@
 
 #include "../../include/burgers_hip.h"
 #include "fom_device.hpp"
+#include "fom_wide.hpp"
 
 namespace {
 
@@ -169,6 +170,94 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void tridiag_solve_kernel(Sol
     store_rows<R>(a.sol + off, N, row0, false, rhs);
 }
 
+// ---- workgroup-per-sample variants (2048 < N <= 8192), see fom_wide.hpp ---------------------
+template <int R>
+__global__ __launch_bounds__(WIDE_THREADS, 1) void fom_wide_kernel(FomArgs a)
+{
+    __shared__ WideLds lds;
+    const int g = threadIdx.x, s = blockIdx.x;              // one workgroup per sample
+    const int N = a.N, row0 = g * R;
+    wide_init(lds, g);
+    const double kap = a.supg ? 0.25 * a.dt : 0.0;
+    const double mu1 = a.mu1[s], mu2 = a.mu2[s];
+    double hfs[R], fdt[R], u[R], gv[R];
+    ElemGeom<R> gm;
+    geom_setup<R>(a.x, N, row0, a.dt, a.E, gm);
+    forcing_setup_general<R>(a.x, N, row0, mu2, a.dt, hfs, fdt);
+    double* hist = a.hist + (size_t)s * (size_t)(a.nsteps + 1) * (size_t)N;
+    load_rows<R>(a.u0 + (size_t)s * N, N, row0, false, u);
+    store_rows<R>(hist, N, row0, false, u);
+    int flags = 0;
+    for (int step = 0; step < a.nsteps; ++step) {
+        wide_mass_rhs<R>(lds, g, gm, N, u, fdt, gv);
+        int k = 0;
+        bool more;                                          // workgroup-uniform: every thread sees the same sums
+        do {
+            double lo[R], di[R], up[R], rhs[R];
+            wide_assemble<R>(lds, g, gm, a.dt, kap, N, mu1, u, gv, hfs, lo, di, up, rhs);
+            wide_tridiag_solve<R>(lds, g, lo, di, up, rhs);
+            double nd = 0.0, nu = 0.0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                u[j] += rhs[j];
+                nd = __builtin_fma(rhs[j], rhs[j], nd);
+                nu = __builtin_fma(u[j], u[j], nu);
+            }
+            wide_sum2(lds, g, nd, nu, nd, nu);
+            ++k;
+            more = (nd > a.tol2 * nu) && (k < a.max_it);
+            if (!(nd - nd == 0.0) || !(nu - nu == 0.0)) flags |= BG_FLAG_NONFINITE;
+        } while (more);
+        if (k >= a.max_it) flags |= BG_FLAG_HIT_CAP;
+        store_rows<R>(hist + (size_t)(step + 1) * N, N, row0, false, u);
+        if (g == 0) a.iters[(size_t)s * a.nsteps + step] = k;
+    }
+    if (g == 0) a.flags[s] = flags;
+}
+
+template <int R>
+__global__ __launch_bounds__(WIDE_THREADS, 1) void fom_assemble_wide_kernel(AsmArgs a)
+{
+    __shared__ WideLds lds;
+    const int g = threadIdx.x, s = blockIdx.x;
+    const int N = a.N, row0 = g * R;
+    wide_init(lds, g);
+    const double kap = a.supg ? 0.25 * a.dt : 0.0;
+    double hfs[R], fdt[R], u[R], un[R], gv[R], lo[R], di[R], up[R], rhs[R];
+    load_rows<R>(a.un + (size_t)s * N, N, row0, false, un);
+    load_rows<R>(a.uk + (size_t)s * N, N, row0, false, u);
+    ElemGeom<R> gm;
+    geom_setup<R>(a.x, N, row0, a.dt, a.E, gm);
+    forcing_setup_general<R>(a.x, N, row0, a.mu2[s], a.dt, hfs, fdt);
+    wide_mass_rhs<R>(lds, g, gm, N, un, fdt, gv);
+    wide_assemble<R>(lds, g, gm, a.dt, kap, N, a.mu1[s], u, gv, hfs, lo, di, up, rhs);
+    store_rows<R>(a.lo + (size_t)s * N, N, row0, false, lo);
+    store_rows<R>(a.di + (size_t)s * N, N, row0, false, di);
+    store_rows<R>(a.up + (size_t)s * N, N, row0, false, up);
+    store_rows<R>(a.rhs + (size_t)s * N, N, row0, false, rhs);
+}
+
+template <int R>
+__global__ __launch_bounds__(WIDE_THREADS, 1) void tridiag_solve_wide_kernel(SolveArgs a)
+{
+    __shared__ WideLds lds;
+    const int g = threadIdx.x, s = blockIdx.x;
+    const int N = a.N, row0 = g * R;
+    wide_init(lds, g);
+    double lo[R], di[R], up[R], rhs[R];
+    const size_t off = (size_t)s * N;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const bool in = row0 + j < N;
+        lo[j] = in ? a.lo[off + row0 + j] : 0.0;
+        di[j] = in ? a.di[off + row0 + j] : 1.0;
+        up[j] = in ? a.up[off + row0 + j] : 0.0;
+        rhs[j] = in ? a.rhs[off + row0 + j] : 0.0;
+    }
+    wide_tridiag_solve<R>(lds, g, lo, di, up, rhs);
+    store_rows<R>(a.sol + off, N, row0, false, rhs);
+}
+
 // ---- batched transpose out[b][c][r] = in[b][r][c] ----------------------------------
 __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in,
                                                         double* __restrict__ out, int rows, int cols)
@@ -210,6 +299,19 @@ int check_launch()
     return BG_OK;
 }
 
+// workgroup-per-sample kernels: 12, 16, 24 or 32 rows per THREAD of a 256-thread workgroup
+constexpr int kWaveMaxN = 64 * 32, kWideMaxN = WIDE_THREADS * 32;
+
+template <typename F>
+int dispatch_wide(int N, F&& f)
+{
+    if (N <= WIDE_THREADS * 12) return f(std::integral_constant<int, 12>{});
+    if (N <= WIDE_THREADS * 16) return f(std::integral_constant<int, 16>{});
+    if (N <= WIDE_THREADS * 24) return f(std::integral_constant<int, 24>{});
+    if (N <= WIDE_THREADS * 32) return f(std::integral_constant<int, 32>{});
+    return BG_ERR_UNSUPPORTED_N;
+}
+
 template <typename F>
 int dispatch_r(int N, F&& f)
 {
@@ -239,14 +341,14 @@ int bg_abi_version(void) { return BG_ABI_VERSION; }
 
 int bg_last_hip_error(void) { return g_last_hip_error; }
 
-int bg_fom_max_n(void) { return 64 * 32; }
+int bg_fom_max_n(void) { return kWideMaxN; }
 
 const char* bg_strerror(int code)
 {
     switch (code) {
         case BG_OK: return "ok";
         case BG_ERR_BAD_ARG: return "bad argument";
-        case BG_ERR_UNSUPPORTED_N: return "N not supported by the wave-per-sample kernels (2 <= N <= 2048)";
+        case BG_ERR_UNSUPPORTED_N: return "N not supported by the fused kernels (2 <= N <= 8192; FD stepper: N <= 2048)";
         case BG_ERR_NONUNIFORM: return "mesh is not uniform";
         case BG_ERR_LAUNCH: return "kernel launch failed (see bg_last_hip_error)";
         case BG_ERR_UNSUPPORTED_R: return "reduced dimension not supported";
@@ -270,6 +372,12 @@ int bg_fom_run(int N, int B, int nsteps, const double* x, const double* u0, cons
     const bool nonuniform = (supg & BG_OPT_NONUNIFORM) != 0;
     const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
+    if (N > kWaveMaxN)                       // one workgroup per sample; the general-mesh arithmetic covers both meshes
+        return dispatch_wide(N, [&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            hipLaunchKernelGGL((fom_wide_kernel<R>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
+            return check_launch();
+        });
     return dispatch_r(N, [&](auto rc) {
         constexpr int R = decltype(rc)::value;
         if (nonuniform)
@@ -295,6 +403,12 @@ int bg_fom_assemble(int N, int B, const double* x, const double* uk, const doubl
     const bool nonuniform = (supg & BG_OPT_NONUNIFORM) != 0;
     const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
+    if (N > kWaveMaxN)
+        return dispatch_wide(N, [&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            hipLaunchKernelGGL((fom_assemble_wide_kernel<R>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
+            return check_launch();
+        });
     return dispatch_r(N, [&](auto rc) {
         constexpr int R = decltype(rc)::value;
         if (nonuniform)
@@ -316,6 +430,12 @@ int bg_tridiag_solve(int N, int B, const double* lo, const double* di, const dou
     SolveArgs a{lo, di, up, rhs, sol, N, B};
     const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
+    if (N > kWaveMaxN)
+        return dispatch_wide(N, [&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            hipLaunchKernelGGL((tridiag_solve_wide_kernel<R>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
+            return check_launch();
+        });
     return dispatch_r(N, [&](auto rc) {
         constexpr int R = decltype(rc)::value;
         hipLaunchKernelGGL((tridiag_solve_kernel<R>), grid, block, 0, st, a);

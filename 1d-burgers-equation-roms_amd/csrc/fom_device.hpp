@@ -215,12 +215,11 @@ __device__ __forceinline__ void forcing_setup_general(const double* __restrict__
     }
 }
 
+// core with the halo values passed in (uL = u of the row below this lane's first, uR = u of the row above its last)
 template <int R>
-__device__ __forceinline__ void mass_rhs_general(const ElemGeom<R>& gm, int N, int row0, const double (&u)[R],
-                                                 const double (&fdt)[R], double (&g)[R])
+__device__ __forceinline__ void mass_rhs_general_core(const ElemGeom<R>& gm, int N, int row0, const double (&u)[R],
+                                                      double uL, double uR, const double (&fdt)[R], double (&g)[R])
 {
-    const double uL = from_lane_below(u[R - 1]);
-    const double uR = from_lane_above(u[0]);
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const double um = (j == 0) ? uL : u[j - 1];
@@ -234,16 +233,21 @@ __device__ __forceinline__ void mass_rhs_general(const ElemGeom<R>& gm, int N, i
 }
 
 template <int R>
-__device__ __forceinline__ void assemble_general(const ElemGeom<R>& gm, double dt, double kap, int N, int row0,
-                                                 double mu1, const double (&u)[R], const double (&g)[R],
-                                                 const double (&hfs)[R], double (&lo)[R], double (&di)[R],
-                                                 double (&up)[R], double (&rhs)[R])
+__device__ __forceinline__ void mass_rhs_general(const ElemGeom<R>& gm, int N, int row0, const double (&u)[R],
+                                                 const double (&fdt)[R], double (&g)[R])
 {
-    const int lane = lane_id();
+    mass_rhs_general_core<R>(gm, N, row0, u, from_lane_below(u[R - 1]), from_lane_above(u[0]), fdt, g);
+}
+
+// assemble_general in two halves so that the halo values can come from anywhere (DPP inside one wave,
+// LDS across the waves of a workgroup).  p1: off-diagonals and the SUPG element terms se[];
+// p2: diagonal, right-hand side, special rows.  `first` marks the lane that owns global row 0.
+template <int R>
+__device__ __forceinline__ void assemble_general_p1(const ElemGeom<R>& gm, double dt, const double (&u)[R], double uL,
+                                                    double uR, const double (&hfs)[R], double (&lo)[R],
+                                                    double (&up)[R], double (&se)[R])
+{
     const double dt6 = dt / 6.0;
-    const double uL = from_lane_below(u[R - 1]);
-    const double uR = from_lane_above(u[0]);
-    double se[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const double ur = (j == R - 1) ? uR : u[j + 1];
@@ -257,7 +261,16 @@ __device__ __forceinline__ void assemble_general(const ElemGeom<R>& gm, double d
         se[j] = t * BG_RCP(mx);
     }
     lo[0] = __builtin_fma(-dt6, __builtin_fma(2.0, u[0], uL), gm.h6[0] - gm.eh[0]);
-    const double seL = from_lane_below(se[R - 1]);
+}
+
+template <int R>
+__device__ __forceinline__ void assemble_general_p2(const ElemGeom<R>& gm, double dt, double kap, int N, int row0,
+                                                    bool first, double mu1, const double (&u)[R], double uL,
+                                                    double uR, double seL, const double (&g)[R],
+                                                    const double (&se)[R], double (&lo)[R], double (&di)[R],
+                                                    double (&up)[R], double (&rhs)[R])
+{
+    const double dt6 = dt / 6.0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const double um = (j == 0) ? uL : u[j - 1];
@@ -281,7 +294,6 @@ __device__ __forceinline__ void assemble_general(const ElemGeom<R>& gm, double d
         l = pad ? 0.0 : l;
         bb = pad ? 0.0 : bb;
         if (j == 0) {
-            const bool first = lane == 0;
             d = first ? 1.0 : d;
             p = first ? 0.0 : p;
             l = first ? 0.0 : l;
@@ -292,6 +304,20 @@ __device__ __forceinline__ void assemble_general(const ElemGeom<R>& gm, double d
         r = __builtin_fma(-p, ur, r);
         lo[j] = l; di[j] = d; up[j] = p; rhs[j] = r;
     }
+}
+
+template <int R>
+__device__ __forceinline__ void assemble_general(const ElemGeom<R>& gm, double dt, double kap, int N, int row0,
+                                                 double mu1, const double (&u)[R], const double (&g)[R],
+                                                 const double (&hfs)[R], double (&lo)[R], double (&di)[R],
+                                                 double (&up)[R], double (&rhs)[R])
+{
+    const double uL = from_lane_below(u[R - 1]);
+    const double uR = from_lane_above(u[0]);
+    double se[R];
+    assemble_general_p1<R>(gm, dt, u, uL, uR, hfs, lo, up, se);
+    const double seL = from_lane_below(se[R - 1]);
+    assemble_general_p2<R>(gm, dt, kap, N, row0, lane_id() == 0, mu1, u, uL, uR, seL, g, se, lo, di, up, rhs);
 }
 
 // One PCR step on normalised equations A x[j-s] + x[j] + C x[j+s] = D; neighbours come from
@@ -315,56 +341,72 @@ __device__ __forceinline__ void pcr_step(double& A, double& C, double& D)
     }
 }
 
-// Pivot-free tridiagonal solve across the wave (Wang partition + PCR on the 64
-// interface unknowns).  In: lo/di/up/rhs.  Out: solution in rhs.  lo, di are clobbered.
+// ---- Wang partition inside one lane, in pieces (shared by the one-wave and the workgroup-wide solver) ----
+// wang_reduce: phase 1 eliminates the sub-diagonal downwards (lo[] becomes the left spike f[], di[] becomes
+// 1/pivot), phase 2 the super-diagonal upwards from row R-3 (gs[] is the right spike).  Returns the last pivot.
 template <int R>
-__device__ __forceinline__ void tridiag_solve(double (&lo)[R], double (&di)[R], const double (&up)[R],
-                                              double (&rhs)[R])
+__device__ __forceinline__ double wang_reduce(double (&lo)[R], double (&di)[R], const double (&up)[R],
+                                              double (&rhs)[R], double (&gs)[R])
+{
+    static_assert(R > 1, "R == 1 has no interior rows");
+    double dp = di[0];
+    di[0] = BG_RCP(dp);
+#pragma unroll
+    for (int j = 1; j < R; ++j) {
+        const double m = lo[j] * di[j - 1];
+        dp = __builtin_fma(-m, up[j - 1], di[j]);
+        di[j] = BG_RCP(dp);
+        rhs[j] = __builtin_fma(-m, rhs[j - 1], rhs[j]);
+        lo[j] = -m * lo[j - 1];
+    }
+    gs[R - 2] = up[R - 2];
+#pragma unroll
+    for (int j = R - 3; j >= 0; --j) {
+        const double t = up[j] * di[j + 1];
+        rhs[j] = __builtin_fma(-t, rhs[j + 1], rhs[j]);
+        lo[j] = __builtin_fma(-t, lo[j + 1], lo[j]);
+        gs[j] = -t * gs[j + 1];
+    }
+    return dp;
+}
+
+// Interface equation A x[p-1] + x[p] + C x[p+1] = D of this lane's last row, closed with the next lane's
+// normalised row 0 (F0, G0, R0 = lo[0]/di[0], gs[0]/di[0], rhs[0]/di[0] over there; zeros past the last lane).
+template <int R>
+__device__ __forceinline__ void wang_interface(const double (&lo)[R], const double (&up)[R], const double (&rhs)[R],
+                                               double dp, double F0, double G0, double R0, double& A, double& C,
+                                               double& D)
+{
+    const double ul = up[R - 1];
+    const double B = __builtin_fma(-ul, F0, dp);
+    const double rb = BG_RCP(B);
+    A = lo[R - 1] * rb;
+    C = -(ul * G0) * rb;
+    D = __builtin_fma(-ul, R0, rhs[R - 1]) * rb;
+}
+
+// Back-substitution: X = this lane's last unknown, XL = the previous lane's.  Solution lands in rhs[].
+template <int R>
+__device__ __forceinline__ void wang_finish(const double (&lo)[R], const double (&di)[R], double (&rhs)[R],
+                                            const double (&gs)[R], double X, double XL)
+{
+#pragma unroll
+    for (int j = 0; j < R - 1; ++j) {
+        double v = __builtin_fma(-lo[j], XL, rhs[j]);
+        v = __builtin_fma(-gs[j], X, v);
+        rhs[j] = v * di[j];
+    }
+    rhs[R - 1] = X;
+}
+
+// PCR over 64 normalised equations, one per lane; returns x of this lane's equation.
+// ds_bpermute costs ~24 cycles per dword on gfx950 against ~6 for a DPP move, so: strides 1 and 2 use
+// wave_shr/wave_shl:1 (once / twice, zero filled), then ONE lane transpose (lane' = 16*(j&3) + (j>>2)) turns
+// the four interleaved stride-4 systems into the four 16-lane DPP rows, where strides 4,8,16,32 are
+// row_shr/shl 1,2,4,8 with zero fill at the row ends (= the system ends).
+__device__ __forceinline__ double pcr64(double A, double C, double D)
 {
     const int lane = lane_id();
-    double A, C, D;           // normalised interface equation: A x[p-1] + x[p] + C x[p+1] = D
-    double gs[R > 1 ? R : 1];
-    if constexpr (R == 1) {
-        const double rb = BG_RCP(di[0]);
-        A = lo[0] * rb; C = up[0] * rb; D = rhs[0] * rb;
-    } else {
-        // phase 1: eliminate sub-diagonal downwards; lo[] becomes the left spike f[],
-        // di[] becomes 1/pivot
-        double dp = di[0];
-        di[0] = BG_RCP(dp);
-#pragma unroll
-        for (int j = 1; j < R; ++j) {
-            const double m = lo[j] * di[j - 1];
-            dp = __builtin_fma(-m, up[j - 1], di[j]);
-            di[j] = BG_RCP(dp);
-            rhs[j] = __builtin_fma(-m, rhs[j - 1], rhs[j]);
-            lo[j] = -m * lo[j - 1];
-        }
-        // phase 2: eliminate super-diagonal upwards from row R-3; gs[] is the right spike
-        gs[R - 2] = up[R - 2];
-#pragma unroll
-        for (int j = R - 3; j >= 0; --j) {
-            const double t = up[j] * di[j + 1];
-            rhs[j] = __builtin_fma(-t, rhs[j + 1], rhs[j]);
-            lo[j] = __builtin_fma(-t, lo[j + 1], lo[j]);
-            gs[j] = -t * gs[j + 1];
-        }
-        // interface equation of this lane's last row, closed with the next lane's row 0
-        const double F0 = from_lane_above(lo[0] * di[0]);
-        const double G0 = from_lane_above(gs[0] * di[0]);
-        const double R0 = from_lane_above(rhs[0] * di[0]);
-        const double ul = up[R - 1];
-        const double B = __builtin_fma(-ul, F0, dp);
-        const double rb = BG_RCP(B);
-        A = lo[R - 1] * rb;
-        C = -(ul * G0) * rb;
-        D = __builtin_fma(-ul, R0, rhs[R - 1]) * rb;
-    }
-    // PCR over the 64 interface equations.  ds_bpermute costs ~24 cycles per dword on gfx950
-    // against ~6 for a DPP move, so: strides 1 and 2 use wave_shr/wave_shl:1 (once / twice, zero
-    // filled), then ONE lane transpose (lane' = 16*(j&3) + (j>>2)) turns the four interleaved
-    // stride-4 systems into the four 16-lane DPP rows, where strides 4,8,16,32 are row_shr/shl
-    // 1,2,4,8 with zero fill at the row ends (= the system ends).
     pcr_step<0x138, 0x130, 1, false>(A, C, D);
     pcr_step<0x138, 0x130, 2, false>(A, C, D);
     {
@@ -375,19 +417,28 @@ __device__ __forceinline__ void tridiag_solve(double (&lo)[R], double (&di)[R], 
     pcr_step<0x112, 0x102, 1, false>(A, C, D);
     pcr_step<0x114, 0x104, 1, false>(A, C, D);
     pcr_step<0x118, 0x108, 1, true>(A, C, D);
-    D = from_lane_rot(D, (16 * (lane & 3) + (lane >> 2)) << 2);
-    const double X = D;                      // this lane's last unknown
+    return from_lane_rot(D, (16 * (lane & 3) + (lane >> 2)) << 2);
+}
+
+// Pivot-free tridiagonal solve across the wave (Wang partition + PCR on the 64
+// interface unknowns).  In: lo/di/up/rhs.  Out: solution in rhs.  lo, di are clobbered.
+template <int R>
+__device__ __forceinline__ void tridiag_solve(double (&lo)[R], double (&di)[R], const double (&up)[R],
+                                              double (&rhs)[R])
+{
     if constexpr (R == 1) {
-        rhs[0] = X;
+        const double rb = BG_RCP(di[0]);
+        rhs[0] = pcr64(lo[0] * rb, up[0] * rb, rhs[0] * rb);
     } else {
-        const double XL = from_lane_below(X);
-#pragma unroll
-        for (int j = 0; j < R - 1; ++j) {
-            double v = __builtin_fma(-lo[j], XL, rhs[j]);
-            v = __builtin_fma(-gs[j], X, v);
-            rhs[j] = v * di[j];
-        }
-        rhs[R - 1] = X;
+        double gs[R];
+        const double dp = wang_reduce<R>(lo, di, up, rhs, gs);
+        const double F0 = from_lane_above(lo[0] * di[0]);
+        const double G0 = from_lane_above(gs[0] * di[0]);
+        const double R0 = from_lane_above(rhs[0] * di[0]);
+        double A, C, D;           // normalised interface equation: A x[p-1] + x[p] + C x[p+1] = D
+        wang_interface<R>(lo, up, rhs, dp, F0, G0, R0, A, C, D);
+        const double X = pcr64(A, C, D);
+        wang_finish<R>(lo, di, rhs, gs, X, from_lane_below(X));
     }
 }
 

@@ -54,8 +54,9 @@ const char *bg_strerror(int code);
 /* hipError_t of the most recent failed launch on the calling thread (0 if none). */
 int bg_last_hip_error(void);
 
-/* Largest N the single-wave FOM / FD kernels handle (rows per lane <= 32, i.e. N <= 2048;
- * beyond 16 rows per lane part of the state spills to AGPRs / scratch). */
+/* Largest N of bg_fom_run / bg_fom_assemble / bg_tridiag_solve: 8192.  N <= 2048 runs one wavefront per
+ * sample (rows per lane <= 32), 2048 < N <= 8192 one 256-thread workgroup per sample (rows per thread <= 32);
+ * beyond 16 rows per lane or thread part of the state spills to AGPRs / scratch.  bg_fd_run: N <= 2048. */
 int bg_fom_max_n(void);
 
 /* ---------------------------------------------------------------------------------

@@ -40,7 +40,7 @@ def test_error_strings_and_argument_validation():
     assert L.bg_fom_run(256, 0, 10, null, null, null, null, 0.05, 0.0, 1e-6, 20, 1, null, null, null, null) == lib.BG_OK
     assert L.bg_fom_run(256, 4, 10, null, null, null, null, -1.0, 0.0, 1e-6, 20, 1, null, null, null, null) == lib.BG_ERR_BAD_ARG
     assert L.bg_transpose_batched(0, 4, 4, null, null, null) == lib.BG_OK
-    assert L.bg_fom_max_n() == 2048
+    assert L.bg_fom_max_n() == 8192
 
 
 def test_facade_rejects_what_the_kernels_do_not_cover():

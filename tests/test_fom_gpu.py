@@ -144,9 +144,11 @@ def test_edge_cases(hip):
     r = fom.fom_run(X, np.ones(256), 4.5, 0.02, 0.05, 0)
     torch.cuda.synchronize()
     assert r.hist.shape == (1, 1, 256) and torch.equal(r.hist[0, 0].cpu(), torch.ones(256, dtype=torch.float64))
-    # N outside the single-wave range and non-uniform meshes are refused, not mis-computed
+    # N beyond the workgroup-per-sample range is refused, not mis-computed
     with pytest.raises(lib.BurgersHipError):
-        fom.fom_run(np.linspace(0, 100, 2500), np.ones(2500), 4.5, 0.02, 0.05, 1)
+        fom.fom_run(np.linspace(0, 100, 9000), np.ones(9000), 4.5, 0.02, 0.05, 1)
+    with pytest.raises(lib.BurgersHipError):              # the FD stepper stays wave-per-sample
+        fom.fd_run(0.0, 100.0, 2500, np.ones(2500), 4.5, 0.02, 0.01, 1)
     Xbad = X.copy(); Xbad[7] = Xbad[9]
     with pytest.raises(ValueError):                     # nodes must be strictly increasing
         fom.fom_run(Xbad, np.ones(256), 4.5, 0.02, 0.05, 1)
@@ -317,3 +319,56 @@ def test_randomised_differential_sweep(hip):
         assert e < TOL and np.array_equal(it, ito), f"case {case}: N={N} B={B} E={E} dt={dt:.4f} rel={e:.2e}"
         assert (fl == 0).all()
     assert worst < TOL
+
+
+WIDE_SIZES = [2049, 3072, 3073, 4096, 5000, 6144, 8192]
+
+
+def test_workgroup_wide_tridiag_solve(hip):
+    """2048 < N <= 8192: Wang partition per thread + PCR across the four waves of a workgroup."""
+    from burgers_hip import fom
+    rng = np.random.default_rng(11)
+    for N in WIDE_SIZES:
+        B = 3
+        lo = rng.uniform(-0.2, 0.1, (B, N)); up = rng.uniform(-0.1, 0.3, (B, N))
+        di = 0.45 + rng.uniform(0, 0.3, (B, N))
+        lo[:, 0] = 0; up[:, -1] = 0
+        rhs = rng.standard_normal((B, N))
+        sol = fom.tridiag_solve(*[torch.tensor(a, device="cuda") for a in (lo, di, up, rhs)]).cpu().numpy()
+        for b in range(B):
+            assert rel_l2(sol[b], br.tridiag_solve(lo[b], di[b], up[b], rhs[b])) < 1e-12, f"N={N}"
+
+
+@pytest.mark.parametrize("N", WIDE_SIZES)
+def test_workgroup_wide_fom(hip, N):
+    """One workgroup per sample: assembly, full runs on uniform and graded meshes, with and without
+    diffusion, against the oracle (rel-L2 <= 1e-10, identical iteration counts)."""
+    from burgers_hip import fom
+    rng = np.random.default_rng(5000 + N)
+    B = 3
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    dt = 0.05 * 512 / N
+    for graded in (False, True):
+        X = np.linspace(0.0, 100.0, N)
+        E = 0.0
+        if graded:
+            w = rng.uniform(0.7, 1.3, N - 1)
+            X = np.concatenate([[0.0], np.cumsum(w)]) * (100.0 / w.sum())
+            E = 0.004
+        if N in (2049, 5000):                               # one Picard assembly, row by row
+            u = 1.0 + 3.0 * rng.random(N)
+            lo, di, up, rhs = [t.cpu().numpy()[0] for t in fom.fom_assemble(X, u, u, mu1[0], mu2[0], dt, E=E)]
+            M3, K3 = br.mass_tridiag(X), br.diffusion_tridiag(X)
+            lo_o, di_o, up_o = br.system_tridiag(M3, K3, br.convection_tridiag(X, u), dt, E)
+            bb = br.tridiag_matvec(*M3, u) + dt * br.forcing_vector(X, mu2[0]) - dt * br.supg_term(X, u, mu2[0])
+            bb[0] = mu1[0]
+            r_o = bb - br.tridiag_matvec(lo_o, di_o, up_o, u)
+            scale = np.abs(di_o).max()
+            assert np.abs(lo - lo_o).max() < 1e-13 * scale and np.abs(di - di_o).max() < 1e-13 * scale
+            assert np.abs(up - up_o).max() < 1e-13 * scale
+            assert np.abs(rhs - r_o).max() < 1e-12 * max(1.0, np.abs(r_o).max())
+        h, it, fl = _run(hip, X, np.ones(N), mu1, mu2, dt, 6, E=E)
+        ho, ito = bc.fom_run(X, np.ones(N), mu1, mu2, dt, 6, E=E)
+        assert np.isfinite(ho).all() and ito.max() < 20
+        assert rel_l2(h, ho) < TOL and np.array_equal(it, ito), f"N={N} graded={graded}"
+        assert (fl == 0).all()
