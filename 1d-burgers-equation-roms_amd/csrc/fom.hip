@@ -171,30 +171,37 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void tridiag_solve_kernel(Sol
 }
 
 // ---- workgroup-per-sample variants (2048 < N <= 8192), see fom_wide.hpp ---------------------
-template <int R>
+template <int R, bool UNI>
 __global__ __launch_bounds__(WIDE_THREADS, 1) void fom_wide_kernel(FomArgs a)
 {
     __shared__ WideLds lds;
     const int g = threadIdx.x, s = blockIdx.x;              // one workgroup per sample
     const int N = a.N, row0 = g * R;
     wide_init(lds, g);
-    const double kap = a.supg ? 0.25 * a.dt : 0.0;
+    const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
+    const MeshConst c = make_mesh_const(h, a.dt, a.E, a.supg);
     const double mu1 = a.mu1[s], mu2 = a.mu2[s];
     double hfs[R], fdt[R], u[R], gv[R];
-    ElemGeom<R> gm;
-    geom_setup<R>(a.x, N, row0, a.dt, a.E, gm);
-    forcing_setup_general<R>(a.x, N, row0, mu2, a.dt, hfs, fdt);
+    ElemGeom<UNI ? 0 : R> gm;
+    if constexpr (UNI) {
+        forcing_setup<R>(a.x, N, row0, mu2, c.h, a.dt, hfs, fdt);
+    } else {
+        geom_setup<R>(a.x, N, row0, a.dt, a.E, gm);
+        forcing_setup_general<R>(a.x, N, row0, mu2, a.dt, hfs, fdt);
+    }
     double* hist = a.hist + (size_t)s * (size_t)(a.nsteps + 1) * (size_t)N;
     load_rows<R>(a.u0 + (size_t)s * N, N, row0, false, u);
     store_rows<R>(hist, N, row0, false, u);
     int flags = 0;
     for (int step = 0; step < a.nsteps; ++step) {
-        wide_mass_rhs<R>(lds, g, gm, N, u, fdt, gv);
+        if constexpr (UNI) wide_mass_rhs_uni<R>(lds, g, c, N, u, fdt, gv);
+        else wide_mass_rhs<R>(lds, g, gm, N, u, fdt, gv);
         int k = 0;
         bool more;                                          // workgroup-uniform: every thread sees the same sums
         do {
             double lo[R], di[R], up[R], rhs[R];
-            wide_assemble<R>(lds, g, gm, a.dt, kap, N, mu1, u, gv, hfs, lo, di, up, rhs);
+            if constexpr (UNI) wide_assemble_uni<R>(lds, g, c, N, mu1, u, gv, hfs, lo, di, up, rhs);
+            else wide_assemble<R>(lds, g, gm, a.dt, c.kap, N, mu1, u, gv, hfs, lo, di, up, rhs);
             wide_tridiag_solve<R>(lds, g, lo, di, up, rhs);
             double nd = 0.0, nu = 0.0;
 #pragma unroll
@@ -215,22 +222,29 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void fom_wide_kernel(FomArgs a)
     if (g == 0) a.flags[s] = flags;
 }
 
-template <int R>
+template <int R, bool UNI>
 __global__ __launch_bounds__(WIDE_THREADS, 1) void fom_assemble_wide_kernel(AsmArgs a)
 {
     __shared__ WideLds lds;
     const int g = threadIdx.x, s = blockIdx.x;
     const int N = a.N, row0 = g * R;
     wide_init(lds, g);
-    const double kap = a.supg ? 0.25 * a.dt : 0.0;
+    const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
+    const MeshConst c = make_mesh_const(h, a.dt, a.E, a.supg);
     double hfs[R], fdt[R], u[R], un[R], gv[R], lo[R], di[R], up[R], rhs[R];
     load_rows<R>(a.un + (size_t)s * N, N, row0, false, un);
     load_rows<R>(a.uk + (size_t)s * N, N, row0, false, u);
-    ElemGeom<R> gm;
-    geom_setup<R>(a.x, N, row0, a.dt, a.E, gm);
-    forcing_setup_general<R>(a.x, N, row0, a.mu2[s], a.dt, hfs, fdt);
-    wide_mass_rhs<R>(lds, g, gm, N, un, fdt, gv);
-    wide_assemble<R>(lds, g, gm, a.dt, kap, N, a.mu1[s], u, gv, hfs, lo, di, up, rhs);
+    if constexpr (UNI) {
+        forcing_setup<R>(a.x, N, row0, a.mu2[s], c.h, a.dt, hfs, fdt);
+        wide_mass_rhs_uni<R>(lds, g, c, N, un, fdt, gv);
+        wide_assemble_uni<R>(lds, g, c, N, a.mu1[s], u, gv, hfs, lo, di, up, rhs);
+    } else {
+        ElemGeom<R> gm;
+        geom_setup<R>(a.x, N, row0, a.dt, a.E, gm);
+        forcing_setup_general<R>(a.x, N, row0, a.mu2[s], a.dt, hfs, fdt);
+        wide_mass_rhs<R>(lds, g, gm, N, un, fdt, gv);
+        wide_assemble<R>(lds, g, gm, a.dt, c.kap, N, a.mu1[s], u, gv, hfs, lo, di, up, rhs);
+    }
     store_rows<R>(a.lo + (size_t)s * N, N, row0, false, lo);
     store_rows<R>(a.di + (size_t)s * N, N, row0, false, di);
     store_rows<R>(a.up + (size_t)s * N, N, row0, false, up);
@@ -372,10 +386,13 @@ int bg_fom_run(int N, int B, int nsteps, const double* x, const double* u0, cons
     const bool nonuniform = (supg & BG_OPT_NONUNIFORM) != 0;
     const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
-    if (N > kWaveMaxN)                       // one workgroup per sample; the general-mesh arithmetic covers both meshes
+    if (N > kWaveMaxN)                       // one workgroup per sample
         return dispatch_wide(N, [&](auto rc) {
             constexpr int R = decltype(rc)::value;
-            hipLaunchKernelGGL((fom_wide_kernel<R>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
+            if (nonuniform)
+                hipLaunchKernelGGL((fom_wide_kernel<R, false>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
+            else
+                hipLaunchKernelGGL((fom_wide_kernel<R, true>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
             return check_launch();
         });
     return dispatch_r(N, [&](auto rc) {
@@ -406,7 +423,10 @@ int bg_fom_assemble(int N, int B, const double* x, const double* uk, const doubl
     if (N > kWaveMaxN)
         return dispatch_wide(N, [&](auto rc) {
             constexpr int R = decltype(rc)::value;
-            hipLaunchKernelGGL((fom_assemble_wide_kernel<R>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
+            if (nonuniform)
+                hipLaunchKernelGGL((fom_assemble_wide_kernel<R, false>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
+            else
+                hipLaunchKernelGGL((fom_assemble_wide_kernel<R, true>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
             return check_launch();
         });
     return dispatch_r(N, [&](auto rc) {

@@ -81,13 +81,12 @@ __device__ __forceinline__ void forcing_setup(const double* __restrict__ x, int 
     }
 }
 
-// g = M u^n + dt F  (constant over the Picard iterations of one time step)
+// g = M u^n + dt F  (constant over the Picard iterations of one time step).  uL / uR: u of the row below
+// this lane's first row / above its last row (0 outside the mesh).
 template <int R, bool FULL>
-__device__ __forceinline__ void mass_rhs(const MeshConst& c, int N, int row0, const double (&u)[R],
-                                         const double (&fdt)[R], double (&g)[R])
+__device__ __forceinline__ void mass_rhs_core(const MeshConst& c, int N, int row0, const double (&u)[R], double uL,
+                                              double uR, const double (&fdt)[R], double (&g)[R])
 {
-    const double uL = from_lane_below(u[R - 1]);
-    const double uR = from_lane_above(u[0]);
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const double um = (j == 0) ? uL : u[j - 1];
@@ -100,17 +99,22 @@ __device__ __forceinline__ void mass_rhs(const MeshConst& c, int N, int row0, co
     }
 }
 
-// One assembly: diagonals lo/di/up of A(u) and rhs = b - A u  (= -R of the reference).
 template <int R, bool FULL>
-__device__ __forceinline__ void assemble(const MeshConst& c, int N, int row0, double mu1,
-                                         const double (&u)[R], const double (&g)[R],
-                                         const double (&hfs)[R], double (&lo)[R], double (&di)[R],
-                                         double (&up)[R], double (&rhs)[R])
+__device__ __forceinline__ void mass_rhs(const MeshConst& c, int N, int row0, const double (&u)[R],
+                                         const double (&fdt)[R], double (&g)[R])
 {
-    const int lane = lane_id();
-    const double uL = from_lane_below(u[R - 1]);
-    const double uR = from_lane_above(u[0]);
-    double se[R];
+    mass_rhs_core<R, FULL>(c, N, row0, u, from_lane_below(u[R - 1]), from_lane_above(u[0]), fdt, g);
+}
+
+// One assembly: diagonals lo/di/up of A(u) and rhs = b - A u  (= -R of the reference), in two halves so that
+// the halo values can come from DPP (one wave per sample) or LDS (one workgroup per sample).
+// p1: off-diagonals and the SUPG element terms se[];  p2: diagonal, right-hand side, special rows.
+// `first` / `last_lane` mark the lanes that own global row 0 / (FULL only) the last row.
+template <int R>
+__device__ __forceinline__ void assemble_p1(const MeshConst& c, const double (&u)[R], double uL, double uR,
+                                            const double (&hfs)[R], double (&lo)[R], double (&up)[R],
+                                            double (&se)[R])
+{
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const double ur = (j == R - 1) ? uR : u[j + 1];
@@ -123,7 +127,14 @@ __device__ __forceinline__ void assemble(const MeshConst& c, int N, int row0, do
         se[j] = t * BG_RCP(mx);
     }
     lo[0] = __builtin_fma(-c.dt6, __builtin_fma(2.0, u[0], uL), c.aoff);
-    const double seL = from_lane_below(se[R - 1]);
+}
+
+template <int R, bool FULL>
+__device__ __forceinline__ void assemble_p2(const MeshConst& c, int N, int row0, bool first, bool last_lane,
+                                            double mu1, const double (&u)[R], double uL, double uR, double seL,
+                                            const double (&g)[R], const double (&se)[R], double (&lo)[R],
+                                            double (&di)[R], double (&up)[R], double (&rhs)[R])
+{
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const double um = (j == 0) ? uL : u[j - 1];
@@ -135,7 +146,7 @@ __device__ __forceinline__ void assemble(const MeshConst& c, int N, int row0, do
         double bb = __builtin_fma(c.kap, se[j], b);
         double l = lo[j], p = up[j];
         // special rows: last real row has no right element; rows >= N are identity
-        const bool is_last = FULL ? (j == R - 1 && lane == 63) : (i == N - 1);
+        const bool is_last = FULL ? (j == R - 1 && last_lane) : (i == N - 1);
         if (FULL ? (j == R - 1) : true) {
             double dl = __builtin_fma(c.dt6, __builtin_fma(2.0, u[j], um), c.dd1);
             d = is_last ? dl : d;
@@ -150,7 +161,6 @@ __device__ __forceinline__ void assemble(const MeshConst& c, int N, int row0, do
             bb = pad ? 0.0 : bb;   // u is 0 on padded rows, so rhs becomes 0
         }
         if (j == 0) {           // Dirichlet row (global row 0)
-            const bool first = lane == 0;
             d = first ? 1.0 : d;
             p = first ? 0.0 : p;
             l = first ? 0.0 : l;
@@ -161,6 +171,21 @@ __device__ __forceinline__ void assemble(const MeshConst& c, int N, int row0, do
         r = __builtin_fma(-p, ur, r);
         lo[j] = l; di[j] = d; up[j] = p; rhs[j] = r;
     }
+}
+
+template <int R, bool FULL>
+__device__ __forceinline__ void assemble(const MeshConst& c, int N, int row0, double mu1,
+                                         const double (&u)[R], const double (&g)[R],
+                                         const double (&hfs)[R], double (&lo)[R], double (&di)[R],
+                                         double (&up)[R], double (&rhs)[R])
+{
+    const int lane = lane_id();
+    const double uL = from_lane_below(u[R - 1]);
+    const double uR = from_lane_above(u[0]);
+    double se[R];
+    assemble_p1<R>(c, u, uL, uR, hfs, lo, up, se);
+    const double seL = from_lane_below(se[R - 1]);
+    assemble_p2<R, FULL>(c, N, row0, lane == 0, lane == 63, mu1, u, uL, uR, seL, g, se, lo, di, up, rhs);
 }
 
 // ------------------------------------------------------------------------------------

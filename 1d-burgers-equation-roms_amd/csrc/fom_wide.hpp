@@ -73,6 +73,32 @@ __device__ __forceinline__ void wide_assemble(WideLds& s, int g, const ElemGeom<
     assemble_general_p2<R>(gm, dt, kap, N, g * R, g == 0, mu1, u, uL, uR, seL, gv, se, lo, di, up, rhs);
 }
 
+// uniform-mesh variants (one element length: no per-element registers, fewer instructions)
+template <int R>
+__device__ __forceinline__ void wide_mass_rhs_uni(WideLds& s, int g, const MeshConst& c, int N, const double (&u)[R],
+                                                  const double (&fdt)[R], double (&gv)[R])
+{
+    double uL, uR;
+    wide_halo_u<R>(s, g, u, uL, uR);
+    mass_rhs_core<R, false>(c, N, g * R, u, uL, uR, fdt, gv);
+    __syncthreads();
+}
+
+template <int R>
+__device__ __forceinline__ void wide_assemble_uni(WideLds& s, int g, const MeshConst& c, int N, double mu1,
+                                                  const double (&u)[R], const double (&gv)[R],
+                                                  const double (&hfs)[R], double (&lo)[R], double (&di)[R],
+                                                  double (&up)[R], double (&rhs)[R])
+{
+    double uL, uR, se[R];
+    wide_halo_u<R>(s, g, u, uL, uR);
+    assemble_p1<R>(c, u, uL, uR, hfs, lo, up, se);
+    s.se[g + WIDE_PAD] = se[R - 1];
+    __syncthreads();
+    const double seL = s.se[g + WIDE_PAD - 1];
+    assemble_p2<R, false>(c, N, g * R, g == 0, false, mu1, u, uL, uR, seL, gv, se, lo, di, up, rhs);
+}
+
 // One PCR step of stride S on equation e, neighbours from the LDS copy `buf` of all equations.
 template <int S>
 __device__ __forceinline__ void wide_pcr_step(const double (&buf)[3][WIDE_LEN], int e, double& A, double& C, double& D)
