@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
 }
 
 // ---- dispatch ------------------------------------------------------------------------
-constexpr int kRowsPerLane[] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 16, 24, 32};
+constexpr int kRowsPerLane[] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 16, 24};
 
 int rows_per_lane(int N)
 {
@@ -313,12 +313,16 @@ int check_launch()
     return BG_OK;
 }
 
-// workgroup-per-sample kernels: 12, 16, 24 or 32 rows per THREAD of a 256-thread workgroup
-constexpr int kWaveMaxN = 64 * 32, kWideMaxN = WIDE_THREADS * 32;
+// workgroup-per-sample kernels: 8, 12, 16, 24 or 32 rows per THREAD of a 256-thread workgroup
+// Measured (tools/time_wide.py, B = 1024): at 32 rows per lane the wave-per-sample kernel spills (N = 2048:
+// 1.1e8 steps/s, N = 1800: 3.4e7) and the workgroup kernel at 8 rows per thread wins (1.29e8 / 1.24e8); at 24
+// rows per lane the wave kernel still wins (N = 1536: 2.7e8 against 1.4e8).
+constexpr int kWaveMaxN = 64 * 24, kWideMaxN = WIDE_THREADS * 32;
 
 template <typename F>
 int dispatch_wide(int N, F&& f)
 {
+    if (N <= WIDE_THREADS * 8) return f(std::integral_constant<int, 8>{});
     if (N <= WIDE_THREADS * 12) return f(std::integral_constant<int, 12>{});
     if (N <= WIDE_THREADS * 16) return f(std::integral_constant<int, 16>{});
     if (N <= WIDE_THREADS * 24) return f(std::integral_constant<int, 24>{});
@@ -342,7 +346,6 @@ int dispatch_r(int N, F&& f)
         case 12: return f(std::integral_constant<int, 12>{});
         case 16: return f(std::integral_constant<int, 16>{});
         case 24: return f(std::integral_constant<int, 24>{});
-        case 32: return f(std::integral_constant<int, 32>{});
         default: return BG_ERR_UNSUPPORTED_N;
     }
 }
@@ -386,7 +389,7 @@ int bg_fom_run(int N, int B, int nsteps, const double* x, const double* u0, cons
     const bool nonuniform = (supg & BG_OPT_NONUNIFORM) != 0;
     const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
-    if (N > kWaveMaxN)                       // one workgroup per sample
+    if (N > kWaveMaxN)                // one workgroup per sample
         return dispatch_wide(N, [&](auto rc) {
             constexpr int R = decltype(rc)::value;
             if (nonuniform)

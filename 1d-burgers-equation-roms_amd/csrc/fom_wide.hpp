@@ -1,5 +1,5 @@
 // fom_wide.hpp -- one WORKGROUP (4 wavefronts) per sample, for meshes beyond one wavefront's
-// registers (2048 < N <= 8192).  Same arithmetic as fom_device.hpp; what changes is where the
+// registers (1536 < N <= 8192).  Same arithmetic as fom_device.hpp; what changes is where the
 // halo values come from and how the 256 interface equations of the Wang partition are solved.
 //
 // Row distribution: thread g = 64*wave + lane of the workgroup owns the R consecutive rows

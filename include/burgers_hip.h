@@ -54,9 +54,9 @@ const char *bg_strerror(int code);
 /* hipError_t of the most recent failed launch on the calling thread (0 if none). */
 int bg_last_hip_error(void);
 
-/* Largest N of bg_fom_run / bg_fom_assemble / bg_tridiag_solve: 8192.  N <= 2048 runs one wavefront per
- * sample (rows per lane <= 32), 2048 < N <= 8192 one 256-thread workgroup per sample (rows per thread <= 32);
- * beyond 16 rows per lane or thread part of the state spills to AGPRs / scratch.  bg_fd_run: N <= 2048. */
+/* Largest N of bg_fom_run / bg_fom_assemble / bg_tridiag_solve: 8192.  N <= 1536 runs one wavefront per
+ * sample (rows per lane <= 24), 1536 < N <= 8192 one 256-thread workgroup per sample (rows per thread <= 32);
+ * at 24 rows per lane and 32 per thread part of the state spills to AGPRs / scratch.  bg_fd_run: N <= 2048. */
 int bg_fom_max_n(void);
 
 /* ---------------------------------------------------------------------------------

@@ -321,11 +321,11 @@ def test_randomised_differential_sweep(hip):
     assert worst < TOL
 
 
-WIDE_SIZES = [2049, 3072, 3073, 4096, 5000, 6144, 8192]
+WIDE_SIZES = [1537, 1800, 2049, 3072, 3073, 4096, 5000, 6144, 8192]
 
 
 def test_workgroup_wide_tridiag_solve(hip):
-    """2048 < N <= 8192: Wang partition per thread + PCR across the four waves of a workgroup."""
+    """1536 < N <= 8192: Wang partition per thread + PCR across the four waves of a workgroup."""
     from burgers_hip import fom
     rng = np.random.default_rng(11)
     for N in WIDE_SIZES:

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.join(REPO, "1d-burgers-equation-roms_amd"))
 import numpy as np, torch
 from burgers_hip import fom
 rng = np.random.default_rng(0)
-for N, B in ((1024, 1024), (2048, 1024), (3072, 256), (4096, 256), (6144, 256), (8192, 256), (4096, 1024)):
+SIZES = eval(os.environ.get('SIZES', '((1024, 1024), (2048, 1024), (3072, 256), (4096, 256), (6144, 256), (8192, 256), (4096, 1024))'))
+for N, B in SIZES:
     X = np.linspace(0, 100, N)
     mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
     dt, nT = 0.05 * 512 / N, 50
