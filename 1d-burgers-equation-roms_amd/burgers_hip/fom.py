@@ -127,11 +127,8 @@ def transpose_batched(t):
     B, R, C = t.shape
     out = torch.empty((B, C, R), dtype=torch.float64, device=device)
     with torch.cuda.device(device):
-        for b0 in range(0, B, 32768):
-            b1 = min(B, b0 + 32768)
-            rc = L.bg_transpose_batched(b1 - b0, R, C, _lib.ptr(t[b0:b1]), _lib.ptr(out[b0:b1]),
-                                        _lib.stream_ptr(device))
-            _lib.check(rc, "bg_transpose_batched")
+        rc = L.bg_transpose_batched(B, R, C, _lib.ptr(t), _lib.ptr(out), _lib.stream_ptr(device))
+    _lib.check(rc, "bg_transpose_batched")
     return out
 
 

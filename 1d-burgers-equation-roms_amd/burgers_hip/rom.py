@@ -68,21 +68,16 @@ def _setup(X, u0, mu1, mu2, dt, E, device, max_n=None):
     fdt = torch.empty((B, N), dtype=torch.float64, device=device)
     hfs = torch.empty((B, N), dtype=torch.float64, device=device)
     with torch.cuda.device(device):
-        for b0 in range(0, B, 32768):
-            b1 = min(B, b0 + 32768)
-            _lib.check(L.bg_forcing_setup(N, b1 - b0, _lib.ptr(Xd), _lib.ptr(mu2d[b0:b1]), float(dt), mesh_opt,
-                                          _lib.ptr(fdt[b0:b1]), _lib.ptr(hfs[b0:b1]), _lib.stream_ptr(device)),
-                       "bg_forcing_setup")
+        _lib.check(L.bg_forcing_setup(N, B, _lib.ptr(Xd), _lib.ptr(mu2d), float(dt), mesh_opt, _lib.ptr(fdt),
+                                      _lib.ptr(hfs), _lib.stream_ptr(device)), "bg_forcing_setup")
     return _Common(L, device, Xd, N, B, mu1d, mu2d, u0d, fdt, hfs, float(dt), float(E), mesh_opt)
 
 
 def _mass_rhs(c, Un, out):
     c.Un = Un.clone()
     with torch.cuda.device(c.device):
-        for b0 in range(0, c.B, 32768):
-            b1 = min(c.B, b0 + 32768)
-            _lib.check(c.L.bg_mass_rhs(c.N, b1 - b0, _lib.ptr(c.X), _lib.ptr(Un[b0:b1]), _lib.ptr(c.fdt[b0:b1]),
-                                       c.mesh_opt, _lib.ptr(out[b0:b1]), c.stream()), "bg_mass_rhs")
+        _lib.check(c.L.bg_mass_rhs(c.N, c.B, _lib.ptr(c.X), _lib.ptr(Un), _lib.ptr(c.fdt), c.mesh_opt, _lib.ptr(out),
+                                   c.stream()), "bg_mass_rhs")
     return out
 
 

@@ -274,22 +274,25 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void tridiag_solve_wide_kernel(Sol
 
 // ---- batched transpose out[b][c][r] = in[b][r][c] ----------------------------------
 __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in,
-                                                        double* __restrict__ out, int rows, int cols)
+                                                        double* __restrict__ out, int nb, int rows, int cols)
 {
     __shared__ double tile[32][33];
-    const size_t base = (size_t)blockIdx.z * rows * cols;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int b = blockIdx.z; b < nb; b += gridDim.z) {        // grid.z is capped at 65535
+        const size_t base = (size_t)b * rows * cols;
 #pragma unroll
-    for (int k = 0; k < 32; k += 8) {
-        int r = r0 + ty + k, cc = c0 + tx;
-        if (r < rows && cc < cols) tile[ty + k][tx] = in[base + (size_t)r * cols + cc];
-    }
-    __syncthreads();
+        for (int k = 0; k < 32; k += 8) {
+            int r = r0 + ty + k, cc = c0 + tx;
+            if (r < rows && cc < cols) tile[ty + k][tx] = in[base + (size_t)r * cols + cc];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 32; k += 8) {
-        int cc = c0 + ty + k, r = r0 + tx;
-        if (r < rows && cc < cols) out[base + (size_t)cc * rows + r] = tile[tx][ty + k];
+        for (int k = 0; k < 32; k += 8) {
+            int cc = c0 + ty + k, r = r0 + tx;
+            if (r < rows && cc < cols) out[base + (size_t)cc * rows + r] = tile[tx][ty + k];
+        }
+        __syncthreads();
     }
 }
 
@@ -470,9 +473,9 @@ int bg_transpose_batched(int B, int rows, int cols, const double* in, double* ou
 {
     if (B < 0 || rows < 0 || cols < 0) return BG_ERR_BAD_ARG;
     if (B == 0 || rows == 0 || cols == 0) return BG_OK;
-    if (!in || !out || B > 65535) return BG_ERR_BAD_ARG;
-    const dim3 grid((cols + 31) / 32, (rows + 31) / 32, B), block(256);
-    hipLaunchKernelGGL(transpose_kernel, grid, block, 0, (hipStream_t)stream, in, out, rows, cols);
+    if (!in || !out) return BG_ERR_BAD_ARG;
+    const dim3 grid((cols + 31) / 32, (rows + 31) / 32, B < 65535 ? B : 65535), block(256);
+    hipLaunchKernelGGL(transpose_kernel, grid, block, 0, (hipStream_t)stream, in, out, B, rows, cols);
     return check_launch();
 }
 

@@ -39,29 +39,30 @@ __global__ __launch_bounds__(256) void forcing_setup_kernel(const double* __rest
                                                             double dt, int nonuniform, double* __restrict__ fdt,
                                                             double* __restrict__ hfs)
 {
-    const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N || b >= B) return;
+    if (i >= N) return;
     const double hu = (x[N - 1] - x[0]) / (double)(N - 1);
-    const double m = mu2[b];
-    double frPrev = 0.0, fl = 0.0, hf = 0.0;
-    if (i > 0) {
-        const double xl = x[i - 1], xr = x[i];
-        const double h = nonuniform ? xr - xl : hu;
-        const double f1 = 0.02 * exp(m * (GP_A * xl + GP_B * xr));
-        const double f2 = 0.02 * exp(m * (GP_B * xl + GP_A * xr));
-        frPrev = (f1 * GP_B + f2 * GP_A) * (0.5 * h);
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {      // grid.y is capped at 65535
+        const double m = mu2[b];
+        double frPrev = 0.0, fl = 0.0, hf = 0.0;
+        if (i > 0) {
+            const double xl = x[i - 1], xr = x[i];
+            const double h = nonuniform ? xr - xl : hu;
+            const double f1 = 0.02 * exp(m * (GP_A * xl + GP_B * xr));
+            const double f2 = 0.02 * exp(m * (GP_B * xl + GP_A * xr));
+            frPrev = (f1 * GP_B + f2 * GP_A) * (0.5 * h);
+        }
+        if (i < N - 1) {
+            const double xl = x[i], xr = x[i + 1];
+            const double h = nonuniform ? xr - xl : hu;
+            const double f1 = 0.02 * exp(m * (GP_A * xl + GP_B * xr));
+            const double f2 = 0.02 * exp(m * (GP_B * xl + GP_A * xr));
+            fl = (f1 * GP_A + f2 * GP_B) * (0.5 * h);
+            hf = h * (f1 + f2);
+        }
+        fdt[(size_t)b * N + i] = dt * (frPrev + fl);
+        hfs[(size_t)b * N + i] = hf;
     }
-    if (i < N - 1) {
-        const double xl = x[i], xr = x[i + 1];
-        const double h = nonuniform ? xr - xl : hu;
-        const double f1 = 0.02 * exp(m * (GP_A * xl + GP_B * xr));
-        const double f2 = 0.02 * exp(m * (GP_B * xl + GP_A * xr));
-        fl = (f1 * GP_A + f2 * GP_B) * (0.5 * h);
-        hf = h * (f1 + f2);
-    }
-    fdt[(size_t)b * N + i] = dt * (frPrev + fl);
-    hfs[(size_t)b * N + i] = hf;
 }
 
 // g = M u^n + dt F      reference: `M @ U[:, n] + At*F` of :683
@@ -70,26 +71,27 @@ __global__ __launch_bounds__(256) void mass_rhs_kernel(const double* __restrict_
                                                        const double* __restrict__ fdt, int N, int B,
                                                        int nonuniform, double* __restrict__ g)
 {
-    const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N || b >= B) return;
-    const double* u = un + (size_t)b * N;
-    if (nonuniform) {
-        double v = 0.0;
-        if (i > 0) v = (x[i] - x[i - 1]) / 6.0 * __builtin_fma(2.0, u[i], u[i - 1]);
-        if (i < N - 1) v = __builtin_fma((x[i + 1] - x[i]) / 6.0, __builtin_fma(2.0, u[i], u[i + 1]), v);
-        g[(size_t)b * N + i] = v + fdt[(size_t)b * N + i];
-        return;
-    }
+    if (i >= N) return;
     const double h6 = (x[N - 1] - x[0]) / (double)(N - 1) / 6.0;
-    double acc;
-    if (i == 0)
-        acc = __builtin_fma(2.0, u[0], u[1]);
-    else if (i == N - 1)
-        acc = __builtin_fma(2.0, u[i], u[i - 1]);
-    else
-        acc = __builtin_fma(4.0, u[i], u[i - 1]) + u[i + 1];
-    g[(size_t)b * N + i] = __builtin_fma(h6, acc, fdt[(size_t)b * N + i]);
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {          // grid.y is capped at 65535
+        const double* u = un + (size_t)b * N;
+        if (nonuniform) {
+            double v = 0.0;
+            if (i > 0) v = (x[i] - x[i - 1]) / 6.0 * __builtin_fma(2.0, u[i], u[i - 1]);
+            if (i < N - 1) v = __builtin_fma((x[i + 1] - x[i]) / 6.0, __builtin_fma(2.0, u[i], u[i + 1]), v);
+            g[(size_t)b * N + i] = v + fdt[(size_t)b * N + i];
+            continue;
+        }
+        double acc;
+        if (i == 0)
+            acc = __builtin_fma(2.0, u[0], u[1]);
+        else if (i == N - 1)
+            acc = __builtin_fma(2.0, u[i], u[i - 1]);
+        else
+            acc = __builtin_fma(4.0, u[i], u[i - 1]) + u[i + 1];
+        g[(size_t)b * N + i] = __builtin_fma(h6, acc, fdt[(size_t)b * N + i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -779,8 +781,8 @@ int bg_forcing_setup(int N, int B, const double* x, const double* mu2, double dt
 {
     if (N < 2 || B < 0) return BG_ERR_BAD_ARG;
     if (B == 0) return BG_OK;
-    if (!x || !mu2 || !fdt || !hfs || B > 65535) return BG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(forcing_setup_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, mu2, N,
+    if (!x || !mu2 || !fdt || !hfs) return BG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(forcing_setup_kernel, dim3((N + 255) / 256, B < 65535 ? B : 65535), dim3(256), 0, (hipStream_t)stream, x, mu2, N,
                        B, dt, (options & BG_OPT_NONUNIFORM) ? 1 : 0, fdt, hfs);
     return check_launch_rom();
 }
@@ -790,8 +792,8 @@ int bg_mass_rhs(int N, int B, const double* x, const double* un, const double* f
 {
     if (N < 2 || B < 0) return BG_ERR_BAD_ARG;
     if (B == 0) return BG_OK;
-    if (!x || !un || !fdt || !g || B > 65535) return BG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(mass_rhs_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, un, fdt, N, B,
+    if (!x || !un || !fdt || !g) return BG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mass_rhs_kernel, dim3((N + 255) / 256, B < 65535 ? B : 65535), dim3(256), 0, (hipStream_t)stream, x, un, fdt, N, B,
                        (options & BG_OPT_NONUNIFORM) ? 1 : 0, g);
     return check_launch_rom();
 }

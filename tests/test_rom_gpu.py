@@ -428,3 +428,22 @@ def test_rom_reduce_randomised_sizes(hip):
                 assert rel_l2(Ar[b], Ar_ref) < 1e-13, (N, r, pname, shared, b)
                 assert rel_l2(brr[b], br_ref) < 1e-12, (N, r, pname, shared, b)
                 assert rel_l2(wtu[b], Wb.T @ U[b]) < 1e-13
+
+
+def test_batches_beyond_one_grid_dimension(hip):
+    """More than 65535 samples: the setup, mass-RHS and transpose kernels stride over the batch."""
+    from burgers_hip import fom, rom
+    N, B = 16, 70001
+    X, _ = mesh(N)
+    rng = np.random.default_rng(3)
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    Un = 1.0 + rng.random((B, N))
+    c = rom._setup(X, Un, mu1, mu2, 0.05, 0.0, None)
+    G = torch.empty((B, N), dtype=torch.float64, device="cuda")
+    rom._mass_rhs(c, _dev(Un), G)
+    M3 = br.mass_tridiag(X)
+    for b in (0, 65534, 65535, 65536, B - 1):
+        ref = br.tridiag_matvec(*M3, Un[b]) + 0.05 * br.forcing_vector(X, mu2[b])
+        assert rel_l2(G[b].cpu().numpy(), ref) < 1e-13
+    t = torch.as_tensor(rng.random((B, 3, 5)), device="cuda")
+    assert torch.equal(fom.transpose_batched(t), t.transpose(1, 2).contiguous())
