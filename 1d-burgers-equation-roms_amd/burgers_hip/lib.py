@@ -27,7 +27,8 @@ BG_ERR_PROJECTION = -6
 BG_ERR_WORKSPACE = -7
 BG_PROJ_GALERKIN, BG_PROJ_LSPG = 0, 1
 BG_FLAG_HIT_CAP, BG_FLAG_NONFINITE = 1, 2
-BG_OPT_SUPG, BG_OPT_NONUNIFORM = 1, 2
+BG_OPT_SUPG, BG_OPT_NONUNIFORM, BG_OPT_W_COLMAJOR = 1, 2, 4
+BG_ACT_NONE, BG_ACT_ELU, BG_ACT_RELU, BG_ACT_TANH = 0, 1, 2, 3
 
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -79,6 +80,8 @@ _SIGNATURES = {
                                           c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
     "bg_lu_solve": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_double,
                                    c_int_p, c_double_p, c_int_p, ctypes.c_void_p]),
+    "bg_mlp_act_jvp": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
 }
 
 _lib = None

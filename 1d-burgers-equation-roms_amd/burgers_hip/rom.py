@@ -81,15 +81,17 @@ def _mass_rhs(c, Un, out):
     return out
 
 
-def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None):
-    """Ar, br (and optionally W^T u) of every active sample.  W: (N, r) shared or (B, N, r)."""
-    r = W.shape[-1]
+def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None, colmajor=False):
+    """Ar, br (and optionally W^T u) of every active sample.  W: (N, r) shared or (B, N, r);
+    with ``colmajor`` the transposed blocks (r, N) / (B, r, N)."""
+    r = W.shape[-2] if colmajor else W.shape[-1]
     if r > c.L.bg_rom_max_r() or c.N > c.L.bg_rom_max_n():
-        return _rom_reduce_library(c, W, U, proj, supg, active, Ar, br, wtu)
+        return _rom_reduce_library(c, W.transpose(-1, -2) if colmajor else W, U, proj, supg, active, Ar, br, wtu)
     stride = 0 if W.dim() == 2 else c.N * r
+    opts = (1 if supg else 0) | c.mesh_opt | (_lib.BG_OPT_W_COLMAJOR if colmajor else 0)
     with torch.cuda.device(c.device):
         rc = c.L.bg_rom_reduce(c.N, c.B, r, proj, _lib.ptr(c.X), _lib.ptr(W), stride, _lib.ptr(U), _lib.ptr(G),
-                               _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, (1 if supg else 0) | c.mesh_opt,
+                               _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, opts,
                                _lib.ptr(active) if active is not None else None, _lib.ptr(Ar), _lib.ptr(br),
                                _lib.ptr(wtu) if wtu is not None else None, c.stream())
     if rc == _lib.BG_ERR_UNSUPPORTED_R:
@@ -490,42 +492,62 @@ class AnnEvaluator:
                 return _mlp_forward_jacobian(self.layers, x)[1].to(torch.float64)
             return ann_jacobian(self.model, x).to(torch.float64)
 
-    # ---- hipGraph replay: the MLP is ~25 tiny launches per evaluation, launch-bound at ROM batch sizes;
-    # both evaluations are captured once per batch shape and replayed from static buffers.
-    def capture(self, B, n, device):
-        self._graphs = None
-        if device.type != "cuda":
+    # ---- value and Jacobian in one pass (recognised fp32 MLP on the device): the value and the n tangent
+    # directions are the 1 + n rows of one matrix per sample, every linear layer is ONE GEMM over B (1 + n)
+    # rows, every activation one bg_mlp_act_jvp launch.  Captured in a hipGraph and replayed.
+    def bind(self, B, n, device, jt_out, qs_out):
+        """jt_out (B, n, nbar) and qs_out (B, nbar): fp64 destinations of dN^T and N(q)."""
+        self.jt_out, self.qs_out = jt_out, qs_out
+        self._graph = None
+        self.fused = self.layers is not None and self.dtype == torch.float32 and device.type == "cuda"
+        if not self.fused:
             return
+        import torch.nn as nn
+        L = _lib.load()
+        self.q_in = torch.zeros((B, n), dtype=torch.float64, device=device)
+        x0 = torch.zeros((B, 1 + n, n), dtype=torch.float32, device=device)
+        x0[:, 1:, :] = torch.eye(n, dtype=torch.float32, device=device)
+        kinds = {type(None): _lib.BG_ACT_NONE, nn.ELU: _lib.BG_ACT_ELU, nn.ReLU: _lib.BG_ACT_RELU, nn.Tanh: _lib.BG_ACT_TANH}
+        plan = [(lin.weight.detach().t().contiguous(), None if lin.bias is None else lin.bias.detach().contiguous(),
+                 kinds[type(act)], float(getattr(act, "alpha", 1.0))) for lin, act in self.layers]
+
+        def run():
+            x0[:, 0, :] = self.q_in                                           # fp64 -> fp32 like q.to(float32)
+            x = x0
+            for wt, bias, kind, alpha in plan:
+                z = torch.matmul(x, wt)                                       # (B, 1+n, h): one GEMM
+                with torch.cuda.device(device):
+                    _lib.check(L.bg_mlp_act_jvp(B, 1 + n, wt.shape[1], _lib.ptr(z), _lib.ptr(bias) if bias is not None else None,
+                                                kind, alpha, _lib.stream_ptr(device)), "bg_mlp_act_jvp")
+                x = z
+            self.qs_out.copy_(x[:, 0, :])
+            self.jt_out.copy_(x[:, 1:, :])
+
+        self._run = run
         try:
-            q_in = torch.zeros((B, n), dtype=torch.float64, device=device)
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
-            with torch.cuda.stream(side):                      # warm-up outside capture (lazy inits, autotune)
-                for _ in range(2):
-                    self.jacobian(q_in); self.forward(q_in)
+            with torch.cuda.stream(side):                      # warm-up outside capture (lazy inits, GEMM selection)
+                run(); run()
             torch.cuda.current_stream(device).wait_stream(side)
-            gj, gf = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gj):
-                j_out = self.jacobian(q_in)
-            with torch.cuda.graph(gf):
-                f_out = self.forward(q_in)
-            self._graphs = (q_in, gj, j_out, gf, f_out)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            self._graph = g
         except Exception:                                      # capture is an optimisation only
-            self._graphs = None
+            self._graph = None
 
-    def jacobian_replay(self, q):
-        if getattr(self, "_graphs", None) is None:
-            return self.jacobian(q)
-        q_in, gj, j_out, _, _ = self._graphs
-        q_in.copy_(q); gj.replay()
-        return j_out
-
-    def forward_replay(self, q):
-        if getattr(self, "_graphs", None) is None:
-            return self.forward(q)
-        q_in, _, _, gf, f_out = self._graphs
-        q_in.copy_(q); gf.replay()
-        return f_out
+    def eval(self, q):
+        """N(q) into qs_out and (dN/dq)^T into jt_out for the batch q (B, n), float64 in and out."""
+        if not self.fused:
+            self.qs_out.copy_(self.forward(q))
+            self.jt_out.copy_(self.jacobian(q).transpose(1, 2))
+            return
+        self.q_in.copy_(q)
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._run()
 
 
 def ann_jacobian(model, q32):
@@ -533,6 +555,31 @@ def ann_jacobian(model, q32):
     Stand-in for the per-sample torch.autograd.functional.jacobian of :1254-1275."""
     from torch.func import jacfwd, vmap
     return vmap(jacfwd(lambda z: model(z.unsqueeze(0)).squeeze(0)))(q32)
+
+
+class _ClosureTangent:
+    """(U_p + U_s dN)^T for a batch, as ONE GEMM: [dN^T | I] (B n x (nbar+n)) . [U_s^T ; U_p^T] ((nbar+n) x N).
+    The output is the column-major per-sample tangent bg_rom_reduce reads with BG_OPT_W_COLMAJOR; the batch of
+    B small (N x nbar) . (nbar x n) GEMMs it replaces ran at 2 TFLOP/s.  reference: :1224, :1361."""
+
+    def __init__(self, Up, Us, B):
+        n, self.nbar = Up.shape[1], Us.shape[1]
+        self.rhs = torch.cat([Us.t(), Up.t()], 0).contiguous()              # (nbar + n, N)
+        self.lhs = torch.zeros((B, n, self.nbar + n), dtype=torch.float64, device=Up.device)
+        self.lhs[:, :, self.nbar:] = torch.eye(n, dtype=torch.float64, device=Up.device)
+
+    @property
+    def jt(self):
+        """The (B, n, nbar) slot for dN^T."""
+        return self.lhs[:, :, :self.nbar]
+
+    def gemm(self):
+        return torch.matmul(self.lhs, self.rhs)
+
+    def __call__(self, dN):
+        """dN: (B, nbar, n) -> (B, n, N)."""
+        self.jt.copy_(dN.transpose(1, 2))
+        return self.gemm()
 
 
 def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG", E=0.0, tol=1e-6, max_it=50,
@@ -547,9 +594,11 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
     Up, Us = _as_dev(U_p, c.device), _as_dev(U_s, c.device)
     n = Up.shape[1]
     UpT, UsT = Up.t().contiguous(), Us.t().contiguous()
+    tangent = _ClosureTangent(Up, Us, c.B)
     model = model.to(device=c.device, dtype=ann_dtype).eval()
     ann = AnnEvaluator(model, n, ann_dtype)
-    ann.capture(c.B, n, c.device)
+    qs = torch.zeros((c.B, Us.shape[1]), dtype=torch.float64, device=c.device)
+    ann.bind(c.B, n, c.device, tangent.jt, qs)
     hist, iters, flags = _alloc_hist(c, nsteps)
     Ar, br, _, G = _workspace(c, n)
     st = _IterState(c, n)
@@ -558,12 +607,11 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
         _mass_rhs(c, U0, G)
         qp = (U0 @ Up).contiguous()                                         # (:1197)
         st.begin_step()
+        ann.eval(qp)                                                        # dN at the first guess (:1219)
         while True:
-            dN = ann.jacobian_replay(qp)                                    # (B, nbar, n), fp32 like :1219
-            dD = (Up.unsqueeze(0) + torch.matmul(Us, dN)).contiguous()      # U_p + U_s dN        (:1224)
-            rom_reduce(c, dD, U0, G, proj, True, st.active, Ar, br, None)
+            rom_reduce(c, tangent.gemm(), U0, G, proj, True, st.active, Ar, br, None, colmajor=True)   # (:1224)
             left = st.solve_update(3, Ar, br, None, qp, tol, max_it)        # q_p += dq           (:1237-1244)
-            qs = ann.forward_replay(qp)                                     # (:1241)
+            ann.eval(qp)                            # q_s = N(q_p) for the decode (:1241) and dN for the next pass
             U0 = (qp @ UpT + qs @ UsT).contiguous()                         # (:1242)
             if left == 0:
                 break
@@ -626,6 +674,7 @@ def pod_rbf_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, X_train, W, epsilon, x_mi
     Up, Us = _as_dev(U_p, c.device), _as_dev(U_s, c.device)
     n = Up.shape[1]
     UpT, UsT = Up.t().contiguous(), Us.t().contiguous()
+    tangent = _ClosureTangent(Up, Us, c.B)
     hist, iters, flags = _alloc_hist(c, nsteps)
     Ar, br, _, G = _workspace(c, n)
     st = _IterState(c, n)
@@ -636,8 +685,7 @@ def pod_rbf_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, X_train, W, epsilon, x_mi
         st.begin_step()
         while True:
             qp = (U0 @ Up).contiguous()                                     # q_p = U_p^T U0        (:1352)
-            dD = (Up.unsqueeze(0) + torch.matmul(Us, rbf.jacobian(qp))).contiguous()     # (:1361)
-            rom_reduce(c, dD, U0, G, proj, True, st.active, Ar, br, None)
+            rom_reduce(c, tangent(rbf.jacobian(qp)), U0, G, proj, True, st.active, Ar, br, None, colmajor=True)   # (:1361)
             left = st.solve_update(1, Ar, br, qp, q, tol_newton, max_newton)   # q_new = q_p + dq, err = |dq|/|q_new|
             act = st.active_before
             U1 = q @ UpT + rbf.value(q) @ UsT                               # (:1378-1381)

@@ -120,6 +120,7 @@ struct ReduceArgs {
     double dt, E;
     int N, B, r, proj, supg, lift_only, nonuniform;
     int w_frag;              // 1: W is in the fragment-major layout of bg_quad_tangent (rom_reduce4 only)
+    int w_colmajor;          // 1: W is [r][N] per sample (BG_OPT_W_COLMAJOR)
 };
 
 template <int S, int NT, int PROJ>
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256, 1) void rom_reduce_kernel(ReduceArgs a)
 #pragma unroll
                 for (int s = 0; s < S + 2; ++s) {
                     const int i = rowbase + s - 1;
-                    frag[t][s] = (i >= 0 && i < N && col < r) ? Wp[(size_t)i * r + col] : 0.0;
+                    frag[t][s] = (i >= 0 && i < N && col < r)
+                                     ? (a.w_colmajor ? Wp[(size_t)col * N + i] : Wp[(size_t)i * r + col]) : 0.0;
                 }
             }
             have_frags = true;
@@ -413,7 +415,8 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
 #pragma unroll
                     for (int s = 0; s < S + 2; ++s) {
                         const int i = rowbase + s - 1;
-                        frag[c][s] = (i >= 0 && i < N && col < r) ? Wp[(size_t)i * r + col] : 0.0;
+                        frag[c][s] = (i >= 0 && i < N && col < r)
+                                         ? (a.w_colmajor ? Wp[(size_t)col * N + i] : Wp[(size_t)i * r + col]) : 0.0;
                     }
                 }
             }
@@ -819,6 +822,7 @@ static int rom_reduce_impl(int N, int B, int r, int projection, const double* x,
     a.Ar = Ar; a.br = br; a.wtu = wtu; a.dt = dt; a.E = E; a.N = N; a.B = B; a.r = r; a.proj = projection;
     a.supg = supg & BG_OPT_SUPG; a.nonuniform = (supg & BG_OPT_NONUNIFORM) ? 1 : 0;
     a.q_in = q_in; a.Uout = Uout; a.lift_only = lift_only; a.w_frag = w_frag;
+    a.w_colmajor = (supg & BG_OPT_W_COLMAJOR) ? 1 : 0;
     if (w_frag && (r > 40 || getenv("BG_ROM_FORCE_16X16"))) return BG_ERR_UNSUPPORTED_R;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess ||

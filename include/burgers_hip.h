@@ -44,10 +44,14 @@ enum { BG_PROJ_GALERKIN = 0, BG_PROJ_LSPG = 1 };
 
 /* option bits of the `supg` / `options` argument of the assembly-carrying entry points */
 enum { BG_OPT_SUPG = 1,        /* include the SUPG vector (fom_burgers, pod_prom_burgers, pod_ann_prom) */
-       BG_OPT_NONUNIFORM = 2   /* x is not a linspace: use the per-element-length kernels          */ };
+       BG_OPT_NONUNIFORM = 2,  /* x is not a linspace: use the per-element-length kernels          */
+       BG_OPT_W_COLMAJOR = 4   /* bg_rom_reduce*: W is [r][N] (per sample), not [N][r]             */ };
 
 /* per-sample status bits written to `flags` */
 enum { BG_FLAG_HIT_CAP = 1, BG_FLAG_NONFINITE = 2 };
+
+/* activation kinds of bg_mlp_act_jvp */
+enum { BG_ACT_NONE = 0, BG_ACT_ELU = 1, BG_ACT_RELU = 2, BG_ACT_TANH = 3 };
 
 int bg_abi_version(void);
 const char *bg_strerror(int code);
@@ -130,7 +134,8 @@ int bg_mass_rhs(int N, int B, const double *x, const double *un, const double *f
  *   reference: FEM/fem_burgers.py:730-762 (pod_prom_burgers), :1134-1156
  *   (pod_quadratic_manifold, supg = 0), :1203-1233 (pod_ann_prom).
  *   W        basis or tangent, [N][r] row-major shared by all samples (w_stride = 0) or
- *            [B][N][r] with w_stride = N*r elements
+ *            [B][N][r] with w_stride = N*r elements; with BG_OPT_W_COLMAJOR in `supg` each
+ *            sample's block is [r][N] instead (what one GEMM dN^T [B*r x m] . U_s^T [m x N] yields)
  *   U        [B][N] current iterate u_k;  G from bg_mass_rhs;  hfs from bg_forcing_setup
  *   active   [B] int32 or NULL: samples with 0 are skipped and their outputs left untouched
  *   Ar       [B][r][r]: W^T A W (BG_PROJ_GALERKIN) or (A W)^T (A W) (BG_PROJ_LSPG)
@@ -200,6 +205,15 @@ int bg_rom_reduce_frag(int N, int B, int r, int projection, const double *x, con
                        const double *U, const double *G, const double *hfs, const double *mu1, double dt,
                        double E, int supg, const int32_t *active, double *Ar, double *br, double *wtu,
                        void *stream);
+
+/* bg_mlp_act_jvp -- activation stage of a forward-mode MLP evaluation, float32, in place
+ *   reference: compute_ann_jacobian FEM/fem_burgers.py:1254-1275 (per-sample autograd Jacobian of the
+ *   POD-ANN closure) and the model call at :1241; the linear layers are library GEMMs over B*n1 rows.
+ *   z      [B][n1][h]: row 0 = W x (no bias yet), rows 1..n1-1 = W (dx/dq_k)
+ *   bias   [h] or NULL
+ *   out:   row 0 <- act(row 0 + bias); rows k >= 1 <- act'(row 0 + bias) * row k
+ *   act    BG_ACT_NONE | BG_ACT_ELU (alpha) | BG_ACT_RELU | BG_ACT_TANH */
+int bg_mlp_act_jvp(int B, int n1, int h, float *z, const float *bias, int act, float alpha, void *stream);
 
 #ifdef __cplusplus
 }

@@ -176,6 +176,16 @@ def test_pod_ann_live_reference(hip):
         jac = rom.ann_jacobian(model, q).cpu().numpy()
     assert np.abs(fwd - g["fwd"]).max() < 2e-5 * max(1.0, np.abs(g["fwd"]).max())
     assert np.abs(jac - g["jac"]).max() < 2e-4 * max(1.0, np.abs(g["jac"]).max())
+    # the fused evaluation (one GEMM per layer over the 1 + n rows, bg_mlp_act_jvp per activation)
+    ev = rom.AnnEvaluator(model.cuda(), q.shape[1], torch.float32)
+    jt = torch.zeros((q.shape[0], q.shape[1], g["fwd"].shape[1]), dtype=torch.float64, device="cuda")
+    qs = torch.zeros((q.shape[0], g["fwd"].shape[1]), dtype=torch.float64, device="cuda")
+    ev.bind(q.shape[0], q.shape[1], torch.device("cuda", 0), jt, qs)
+    assert ev.fused
+    ev.eval(q.double())
+    torch.cuda.synchronize()
+    assert np.abs(qs.cpu().numpy() - g["fwd"]).max() < 2e-5 * max(1.0, np.abs(g["fwd"]).max())
+    assert np.abs(jt.transpose(1, 2).cpu().numpy() - g["jac"]).max() < 2e-4 * max(1.0, np.abs(g["jac"]).max())
     res = rom.pod_ann_run(X, np.ones(512), float(g["mu1"]), float(g["mu2"]), float(g["At"]), int(g["nT"]),
                           g["U_p"], g["U_s"], model)
     torch.cuda.synchronize()
@@ -447,3 +457,31 @@ def test_batches_beyond_one_grid_dimension(hip):
         assert rel_l2(G[b].cpu().numpy(), ref) < 1e-13
     t = torch.as_tensor(rng.random((B, 3, 5)), device="cuda")
     assert torch.equal(fom.transpose_batched(t), t.transpose(1, 2).contiguous())
+
+
+@pytest.mark.parametrize("N,r", [(512, 5), (300, 17), (512, 40), (128, 44)])
+def test_rom_reduce_column_major_basis(hip, N, r):
+    """BG_OPT_W_COLMAJOR: per-sample (r, N) blocks give bit-identical results to the (N, r) layout."""
+    from burgers_hip import rom
+    rng = np.random.default_rng(N + r)
+    X, _ = mesh(N)
+    B = 5
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    U = 1.0 + 4.0 * rng.random((B, N)); Un = 1.0 + 4.0 * rng.random((B, N))
+    c = rom._setup(X, Un, mu1, mu2, 0.05, 0.0, None)
+    G = torch.empty((B, N), dtype=torch.float64, device="cuda")
+    rom._mass_rhs(c, _dev(Un), G)
+    for W in (rng.standard_normal((B, N, r)), rng.standard_normal((N, r))):
+        Wd = _dev(W)
+        WdT = Wd.transpose(-1, -2).contiguous()
+        for proj in (0, 1):
+            out = []
+            for colmajor in (False, True):
+                Ar = torch.zeros((B, r, r), dtype=torch.float64, device="cuda")
+                brr = torch.zeros((B, r), dtype=torch.float64, device="cuda")
+                wtu = torch.zeros((B, r), dtype=torch.float64, device="cuda")
+                rom.rom_reduce(c, WdT if colmajor else Wd, _dev(U), G, proj, True, None, Ar, brr, wtu, colmajor=colmajor)
+                out.append((Ar, brr, wtu))
+            torch.cuda.synchronize()
+            for a, b in zip(*out):
+                assert torch.equal(a, b)
