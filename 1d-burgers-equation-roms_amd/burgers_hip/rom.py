@@ -658,8 +658,9 @@ class RbfClosure:
         else:
             k = (1.0 + (self.eps ** 2) * (r ** 2)) ** (-0.5)
             G = (-(self.eps ** 2)) * ((k ** 3).unsqueeze(-1) * diff)
-        J = torch.matmul(self.W.t(), G) * (2.0 / self.dx).reshape(1, 1, -1)     # (B, nbar, n)
-        return (0.5 * self.dy).reshape(1, -1, 1) * J
+        # J^T as ONE GEMM over B n rows: (B, n, Ns) . (Ns, nbar); the broadcast form W^T . G is B small GEMMs
+        JT = torch.matmul(G.transpose(1, 2), self.W) * (2.0 / self.dx).reshape(1, -1, 1)
+        return ((0.5 * self.dy).reshape(1, 1, -1) * JT).transpose(1, 2)         # (B, nbar, n) view
 
 
 def pod_rbf_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, X_train, W, epsilon, x_min, x_max, y_min, y_max,
