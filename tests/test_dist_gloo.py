@@ -119,3 +119,7 @@ def test_pod_basis_reproduces_committed_modes():
     Phi, H, q = pod.build_quadratic_manifold(S, 21, alpha=1e-2)
     Phi_ref = np.load("/root/reference/Quadratic_manifold/Phi.npy")
     assert np.abs(pod.align_signs(Phi, torch.from_numpy(Phi_ref)).numpy() - Phi_ref).max() < 1e-9
+    H_ref = np.ascontiguousarray(np.load("/root/reference/Quadratic_manifold/H.npy"))
+    sg = np.sign((Phi.numpy() * Phi_ref).sum(0))
+    I, J = np.triu_indices(21)
+    assert np.linalg.norm(H.numpy() * (sg[I] * sg[J]) - H_ref) < 1e-8 * np.linalg.norm(H_ref)

@@ -485,3 +485,34 @@ def test_rom_reduce_column_major_basis(hip, N, r):
             torch.cuda.synchronize()
             for a, b in zip(*out):
                 assert torch.equal(a, b)
+
+
+def test_offline_basis_builders_on_device(hip):
+    """POD basis and quadratic-manifold fit built on the device from a device-resident sweep agree with a
+    host LAPACK SVD of the same snapshots: every mode down to sigma/sigma_1 = 1e-8 (rocSOLVER's own SVD
+    loses those: 1e-1 error, tools/time_pod.py), H to 1e-7.  reference: POD/pod.py:80-90,
+    Quadratic_manifold/build_quadratic_manifold.py:25-48."""
+    from burgers_hip import fom, pod
+    N = 256
+    X, _ = mesh(N)
+    m1, m2 = np.meshgrid(np.linspace(4.25, 5.5, 3), np.linspace(0.015, 0.03, 2), indexing="ij")
+    res = fom.fom_run(X, np.ones(N), m1.ravel(), m2.ravel(), 0.05, 200)
+    S = pod.snapshot_matrix(res.hist).contiguous()
+    Sc = S.cpu()
+    Uc, sc, _ = torch.linalg.svd(Sc, full_matrices=False)
+    U, s, s_all = pod.pod_basis(S, epsilon_squared=1e-6)
+    K = pod.n_modes_for_tolerance(sc, 1e-6)
+    assert U.shape == (N, K) and U.is_cuda
+    assert float(((s_all.cpu() - sc).abs() / sc[0]).max()) < 1e-13
+    Ud, _, _ = pod.thin_svd(S)
+    keep = int((sc / sc[0] > 1e-8).sum())
+    assert keep > 100
+    Ua = pod.align_signs(Ud[:, :keep].cpu(), Uc[:, :keep])
+    assert float((Ua - Uc[:, :keep]).abs().max()) < 1e-8
+    assert float((Ua[:, :K] - Uc[:, :K]).abs().max()) < 1e-11
+    n = 12
+    Pg, Hg, _ = pod.build_quadratic_manifold(S, n, alpha=1e-2)
+    Pc, Hc, _ = pod.build_quadratic_manifold(Sc, n, alpha=1e-2)
+    sg = torch.sign((Pg.cpu() * Pc).sum(0)); I, J = np.triu_indices(n)
+    assert float((Pg.cpu() * sg - Pc).abs().max()) < 1e-11
+    assert float(torch.linalg.norm(Hg.cpu() * (sg[I] * sg[J]) - Hc) / torch.linalg.norm(Hc)) < 1e-7
