@@ -731,7 +731,7 @@ def local_prom_run(X, u0, mu1, mu2, dt, nsteps, centers, local_bases, U_global, 
     for n in range(nsteps):
         _mass_rhs(c, U0, G)
         qg = U0 @ Ug                                                          # (:1011)
-        cid = torch.cdist(qg, cen).argmin(dim=1)                              # kmeans.predict  (:1012)
+        cid = torch.cdist(qg, cen, compute_mode="donot_use_mm_for_euclid_dist").argmin(dim=1)   # kmeans.predict (:1012)
         slot = slot_of[cid]
         if bool((slot < 0).any()):
             raise KeyError("a predicted cluster has no local basis")
