@@ -29,6 +29,7 @@ BG_PROJ_GALERKIN, BG_PROJ_LSPG = 0, 1
 BG_FLAG_HIT_CAP, BG_FLAG_NONFINITE = 1, 2
 BG_OPT_SUPG, BG_OPT_NONUNIFORM, BG_OPT_W_COLMAJOR = 1, 2, 4
 BG_ACT_NONE, BG_ACT_ELU, BG_ACT_RELU, BG_ACT_TANH = 0, 1, 2, 3
+BG_COUNTER_SLOTS, BG_COUNTER_STRIDE = 16, 32
 
 _SIGNATURES = {
     # name: (restype, argtypes)

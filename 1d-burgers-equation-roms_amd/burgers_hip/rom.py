@@ -167,7 +167,7 @@ class _IterState:
         self.k = torch.zeros((c.B,), **i32)
         self.flags = torch.zeros((c.B,), **i32)
         self.info = torch.zeros((c.B,), **i32)
-        self.counter = torch.zeros((2,), **i32)
+        self.counter = torch.zeros((2, _lib.BG_COUNTER_SLOTS * _lib.BG_COUNTER_STRIDE), **i32)   # partial counts: still active | singular
         self.dq = torch.zeros((c.B, n), dtype=torch.float64, device=c.device)
 
     # Converged samples are skipped ON THE DEVICE (active mask), so the host does not have to
@@ -215,7 +215,7 @@ class _IterState:
         poll = (self.launched >= max_it or self.launched == self.POLL_FIRST or
                 (self.launched > self.POLL_FIRST and (self.launched - self.POLL_FIRST) % self.POLL_EVERY == 0))
         if poll:
-            self.counter[0:1].zero_()       # [1] (singular systems) keeps accumulating until read
+            self.counter[0].zero_()         # row 1 (singular systems) keeps accumulating until read
         with torch.cuda.device(c.device):
             rc = c.L.bg_lu_solve_update(q.shape[1], c.B, _lib.ptr(Ar), _lib.ptr(br), mode,
                                         _lib.ptr(wtu) if wtu is not None else None, _lib.ptr(q), _lib.ptr(self.dq),
@@ -226,7 +226,7 @@ class _IterState:
         _lib.check(rc, "bg_lu_solve_update")
         if not poll:
             return -1
-        n_active, n_singular = self.counter.cpu().tolist()
+        n_active, n_singular = self.counter.cpu().sum(1).tolist()      # 4 KB readback, summed on the host
         if n_singular:
             raise SingularReducedSystem("Singular matrix")
         return n_active

@@ -662,7 +662,7 @@ struct LuArgs {
     int32_t* active_io;   // [B]
     int32_t* iters;       // [B]
     int32_t* flags;       // [B]
-    int32_t* counter;     // [1]  number of samples still active after this call
+    int32_t* counter;     // [2 * BG_COUNTER_SLOTS * BG_COUNTER_STRIDE]  partial counts: still active | singular (see burgers_hip.h)
 };
 
 __device__ __forceinline__ double readlane_f64(double v, int srclane)
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(LuArgs a)
     if (lane < n) a.x[(size_t)sys * n + lane] = xout;
     if (lane == 0 && a.info && info) a.info[sys] = info;
     if (a.mode != 0) {
-        if (lane == 0 && info) atomicAdd(a.counter + 1, 1);
+        if (lane == 0 && info) atomicAdd(a.counter + (BG_COUNTER_SLOTS + (sys & (BG_COUNTER_SLOTS - 1))) * BG_COUNTER_STRIDE, 1);
         // reference updates: POD  q = Phi^T U0 + dq, err = |dq|/|q|                    (:770-776)
         //                    quad q += dq, rel = |dq|/max(1e-14,|q|), stop if rel<tol   (:1161-1169)
         //                    ANN  q_p += dq, err = |dq|/(|q_p|+1e-14)                   (:1237-1244)
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(LuArgs a)
             if (!(err - err == 0.0)) f |= BG_FLAG_NONFINITE;
             if (k >= a.max_it && ((a.mode == 2) ? !(err < a.tol) : true)) f |= BG_FLAG_HIT_CAP;
             if (f) a.flags[sys] |= f;
-            if (more) atomicAdd(a.counter, 1);
+            if (more) atomicAdd(a.counter + (sys & (BG_COUNTER_SLOTS - 1)) * BG_COUNTER_STRIDE, 1);   // one cache line per slot
         }
     }
 }

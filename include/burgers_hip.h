@@ -50,6 +50,9 @@ enum { BG_OPT_SUPG = 1,        /* include the SUPG vector (fom_burgers, pod_prom
 /* per-sample status bits written to `flags` */
 enum { BG_FLAG_HIT_CAP = 1, BG_FLAG_NONFINITE = 2 };
 
+#define BG_COUNTER_SLOTS 16   /* partial counters of bg_lu_solve_update ...          */
+#define BG_COUNTER_STRIDE 32  /* ... one per 128-byte line (stride in int32 elements) */
+
 /* activation kinds of bg_mlp_act_jvp */
 enum { BG_ACT_NONE = 0, BG_ACT_ELU = 1, BG_ACT_RELU = 2, BG_ACT_TANH = 3 };
 
@@ -170,8 +173,11 @@ int bg_rom_lift(int N, int B, int r, const double *x, const double *Phi, const d
  *   mode 1 (pod_prom_burgers :770-776):       q = wtu + dq;  err = |dq|/|q|;            go on while err > tol and k < max_it
  *   mode 2 (pod_quadratic_manifold :1161-69): q += dq;       err = |dq|/max(1e-14,|q|); stop when err < tol (cap max_it)
  *   mode 3 (pod_ann_prom :1237-1244):         q += dq;       err = |dq|/(|q|+1e-14);    go on while err > tol and k < max_it
- *   iters[b] += 1; active[b] <- go on; flags[b] |= BG_FLAG_*; counter[0] += (#samples still
- *   active), counter[1] += (#singular systems); the caller zeroes counter before the call. */
+ *   iters[b] += 1; active[b] <- go on; flags[b] |= BG_FLAG_*.
+ *   counter [2][BG_COUNTER_SLOTS][BG_COUNTER_STRIDE] int32, element [.][s][0] used: row 0 sums to the
+ *   number of samples still active, row 1 to the number of singular systems (sample b adds to slot
+ *   b % SLOTS, one cache line per slot: 4096 atomics on one line cost 8 us); the caller zeroes it
+ *   before the call and sums the slots. */
 int bg_lu_solve_update(int n, int B, const double *A, const double *rhs, int mode, const double *wtu,
                        double *q, double *dq, double tol, int max_it, int32_t *active, int32_t *iters,
                        int32_t *flags, int32_t *counter, int32_t *info, void *stream);
