@@ -81,6 +81,8 @@ _SIGNATURES = {
                                           c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
     "bg_lu_solve": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_double,
                                    c_int_p, c_double_p, c_int_p, ctypes.c_void_p]),
+    "bg_jacobi_sweep": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_int_p, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_double, c_int_p, ctypes.c_void_p]),
     "bg_mlp_act_jvp": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
 }

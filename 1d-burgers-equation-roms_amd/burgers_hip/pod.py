@@ -29,22 +29,60 @@ def n_modes_for_tolerance(s, epsilon_squared):
     return int(hit[0]) + 1 if len(hit) else 1
 
 
-def thin_svd(A):
-    """U, s, Vh of a wide matrix A (m x M), M >> m (snapshot matrices are N x B (nT+1)).
+def _round_robin(m):
+    """(m' - 1, m'/2, 2) int32 pairs of a round-robin tournament over m rows (m' = m rounded up to even;
+    the dummy player shows as -1)."""
+    n = m + (m & 1)
+    idx = list(range(n))
+    steps = []
+    for _ in range(n - 1):
+        steps.append([(idx[i], idx[n - 1 - i]) for i in range(n // 2)])
+        idx = [idx[0], idx[-1]] + idx[1:-1]
+    t = torch.tensor(steps, dtype=torch.int32)
+    t[t >= m] = -1
+    return t
 
-    A^T = Q R on the device (Householder QR, O(M m^2)), then the SVD of the m x m core R = Ur s Vr^T, and
-    A = Vr s (Q Ur)^T.  The core goes to LAPACK on the host: rocSOLVER's SVD is a Jacobi eigensolver on the
-    Gram matrix, measured absolute accuracy 1e-9 sigma_max (tools/time_pod.py), which loses the singular
-    triplets a 1e-6 energy tolerance still keeps; LAPACK gesdd is what the reference's np.linalg.svd runs
-    (POD/pod.py:84).  5 MB cross PCIe for m = 512; the flops that scale with the snapshot count stay on
-    the device."""
+
+def jacobi_svd(R, tol=1e-15, max_sweeps=40):
+    """SVD of a square device matrix by one-sided Jacobi on the HIP kernel bg_jacobi_sweep.
+    Returns U, s, Vh with R = U diag(s) Vh, s descending.  The rotations act on the ROWS of R, i.e.
+    on the columns of R^T: R^T J = W with orthogonal columns  =>  R = J (W^T): left vectors J, right W/|W|."""
+    from . import lib as _lib
+    L = _lib.load()
+    m = R.shape[0]
+    G = R.contiguous().clone()
+    Jt = torch.eye(m, dtype=torch.float64, device=R.device)
+    pairs = _round_robin(m).to(R.device)
+    rot = torch.zeros((1,), dtype=torch.int32, device=R.device)
+    with torch.cuda.device(R.device):
+        for _ in range(max_sweeps):
+            rot.zero_()
+            _lib.check(L.bg_jacobi_sweep(m, m, _lib.ptr(G), _lib.ptr(Jt), _lib.ptr(pairs), pairs.shape[0], pairs.shape[1],
+                                         float(tol), _lib.ptr(rot), _lib.stream_ptr(R.device)), "bg_jacobi_sweep")
+            if int(rot.item()) == 0:
+                break
+    s = torch.linalg.vector_norm(G, dim=1)
+    order = torch.argsort(s, descending=True)
+    s, G, Jt = s[order], G[order], Jt[order]
+    Vh = G / torch.clamp(s, min=torch.finfo(torch.float64).tiny)[:, None]
+    return Jt.t().contiguous(), s, Vh
+
+
+def thin_svd(A):
+    """U, s, Vh of a wide matrix A (m x M), M >> m (snapshot matrices are N x B (nT+1)), on A's device.
+
+    A^T = Q R by Householder QR (O(M m^2), rocSOLVER), then the SVD of the m x m core by one-sided Jacobi
+    (bg_jacobi_sweep), and A = R^T Q^T = Vr s (Q Ur)^T.  rocSOLVER's own SVD is a Jacobi eigensolver on the
+    Gram matrix: measured absolute accuracy 1e-9 sigma_max (tools/time_pod.py), which loses the singular
+    triplets a 1e-6 energy tolerance still keeps.  On CPU tensors (tests, fixtures) LAPACK does the lot."""
     m, M = A.shape
-    if M < 2 * m:
-        U, s, Vh = torch.linalg.svd(A.cpu(), full_matrices=False)
-        return U.to(A.device), s.to(A.device), Vh.to(A.device)
-    Q, R = torch.linalg.qr(A.t(), mode="reduced")            # (M, m), (m, m)
-    Ur, s, VrT = torch.linalg.svd(R.cpu(), full_matrices=False)
-    Ur, s, VrT = Ur.to(A.device), s.to(A.device), VrT.to(A.device)
+    if not A.is_cuda:
+        return torch.linalg.svd(A, full_matrices=False)
+    if m > M:                                                     # tall: work on the transpose
+        V, s, Uh = thin_svd(A.t())
+        return Uh.t().contiguous(), s, V.t().contiguous()
+    Q, R = torch.linalg.qr(A.t(), mode="reduced")                # (M, m), (m, m)
+    Ur, s, VrT = jacobi_svd(R)
     return VrT.t().contiguous(), s, (Q @ Ur).t()
 
 

@@ -221,6 +221,19 @@ int bg_rom_reduce_frag(int N, int B, int r, int projection, const double *x, con
  *   act    BG_ACT_NONE | BG_ACT_ELU (alpha) | BG_ACT_RELU | BG_ACT_TANH */
 int bg_mlp_act_jvp(int B, int n1, int h, float *z, const float *bias, int act, float alpha, void *stream);
 
+/* bg_jacobi_sweep -- n_steps steps of a one-sided (Hestenes) Jacobi SVD sweep, the accurate small core of
+ * the snapshot SVD (reference: np.linalg.svd at POD/pod.py:84, build_quadratic_manifold.py:29).
+ *   G      [m][ld] row-major: the m rows are orthogonalised in place by plane rotations
+ *   J      [m][ld]: receives the same rotations (start from the identity)
+ *   pairs  [n_steps][n_pairs][2] int32: disjoint row pairs of every step (round-robin ordering);
+ *          an entry < 0 marks a bye
+ *   tol    rows p, q are rotated when |g_p . g_q| > tol |g_p| |g_q|
+ *   rotations [1] int32: += number of rotations applied (0 after a full sweep = converged)
+ * After convergence the row norms of G are the singular values of the input, G[j]/|G[j]| its left
+ * singular vectors (as rows), J its right singular vectors (as rows). */
+int bg_jacobi_sweep(int m, int ld, double *G, double *J, const int32_t *pairs, int n_steps, int n_pairs,
+                    double tol, int32_t *rotations, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

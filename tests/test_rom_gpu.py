@@ -488,8 +488,8 @@ def test_rom_reduce_column_major_basis(hip, N, r):
 
 
 def test_offline_basis_builders_on_device(hip):
-    """POD basis and quadratic-manifold fit built on the device from a device-resident sweep agree with a
-    host LAPACK SVD of the same snapshots: every mode down to sigma/sigma_1 = 1e-8 (rocSOLVER's own SVD
+    """POD basis (device QR + one-sided Jacobi, bg_jacobi_sweep) and quadratic-manifold fit built on the device
+    from a device-resident sweep agree with a host LAPACK SVD of the same snapshots: every mode down to sigma/sigma_1 = 1e-8 (rocSOLVER's own SVD
     loses those: 1e-1 error, tools/time_pod.py), H to 1e-7.  reference: POD/pod.py:80-90,
     Quadratic_manifold/build_quadratic_manifold.py:25-48."""
     from burgers_hip import fom, pod
@@ -503,7 +503,7 @@ def test_offline_basis_builders_on_device(hip):
     U, s, s_all = pod.pod_basis(S, epsilon_squared=1e-6)
     K = pod.n_modes_for_tolerance(sc, 1e-6)
     assert U.shape == (N, K) and U.is_cuda
-    assert float(((s_all.cpu() - sc).abs() / sc[0]).max()) < 1e-13
+    assert float(((s_all.cpu() - sc).abs() / sc[0]).max()) < 1e-12
     Ud, _, _ = pod.thin_svd(S)
     keep = int((sc / sc[0] > 1e-8).sum())
     assert keep > 100
@@ -516,3 +516,21 @@ def test_offline_basis_builders_on_device(hip):
     sg = torch.sign((Pg.cpu() * Pc).sum(0)); I, J = np.triu_indices(n)
     assert float((Pg.cpu() * sg - Pc).abs().max()) < 1e-11
     assert float(torch.linalg.norm(Hg.cpu() * (sg[I] * sg[J]) - Hc) / torch.linalg.norm(Hc)) < 1e-7
+
+
+@pytest.mark.parametrize("m", [1, 2, 7, 64, 129])
+def test_jacobi_svd_core(hip, m):
+    """bg_jacobi_sweep on graded random matrices (condition 1e10): singular values, orthogonal factors,
+    reconstruction, all at the eps * sigma_1 level the input itself carries."""
+    from burgers_hip import pod
+    rng = np.random.default_rng(m)
+    U0, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    V0, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    s0 = np.logspace(0, -10, m) if m > 1 else np.array([3.0])
+    A = (U0 * s0) @ V0.T
+    U, s, Vh = pod.jacobi_svd(_dev(A))
+    U, s, Vh = U.cpu().numpy(), s.cpu().numpy(), Vh.cpu().numpy()
+    assert np.all(np.diff(s) <= 0)
+    assert np.abs(s - s0).max() / s0[0] < 1e-13 and np.abs(s / s0 - 1).max() < 1e-5    # A itself carries eps*sigma_1
+    assert np.abs(U.T @ U - np.eye(m)).max() < 1e-13 and np.abs(Vh @ Vh.T - np.eye(m)).max() < 1e-13
+    assert np.abs((U * s) @ Vh - A).max() < 1e-13
