@@ -6,6 +6,7 @@
 """
 from __future__ import annotations
 
+import functools
 import os
 
 import numpy as np
@@ -29,6 +30,7 @@ def n_modes_for_tolerance(s, epsilon_squared):
     return int(hit[0]) + 1 if len(hit) else 1
 
 
+@functools.lru_cache(maxsize=8)
 def _round_robin(m):
     """(m' - 1, m'/2, 2) int32 pairs of a round-robin tournament over m rows (m' = m rounded up to even;
     the dummy player shows as -1)."""
