@@ -35,14 +35,14 @@ def _round_robin(m):
     """(m' - 1, m'/2, 2) int32 pairs of a round-robin tournament over m rows (m' = m rounded up to even;
     the dummy player shows as -1)."""
     n = m + (m & 1)
-    idx = list(range(n))
-    steps = []
-    for _ in range(n - 1):
-        steps.append([(idx[i], idx[n - 1 - i]) for i in range(n // 2)])
-        idx = [idx[0], idx[-1]] + idx[1:-1]
-    t = torch.tensor(steps, dtype=torch.int32)
-    t[t >= m] = -1
-    return t
+    idx = np.arange(n)
+    steps = np.empty((n - 1, n // 2, 2), dtype=np.int32)
+    for r in range(n - 1):
+        steps[r, :, 0] = idx[:n // 2]
+        steps[r, :, 1] = idx[::-1][:n // 2]
+        idx = np.concatenate([idx[:1], idx[-1:], idx[1:-1]])
+    steps[steps >= m] = -1
+    return torch.from_numpy(steps)
 
 
 def jacobi_svd(R, tol=1e-15, max_sweeps=40):
