@@ -30,3 +30,21 @@ def test_bench_json_contract(hip):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 0 and d["rel_l2_vs_cpu_ref"] < 1e-10 and d["iters_match_cpu_ref"] is True
+
+
+def test_bench_two_ranks_rehearsal(hip):
+    """The driver's multi-GPU launch line with two ranks on this box's one GPU (gloo for the two scalar
+    reductions, since RCCL refuses two ranks per device): barrier + max-over-ranks timing, shard-per-rank
+    workload, whole-job value."""
+    env = dict(os.environ, BG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "64", "--time-steps", "20"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 128 and "cpu_baseline" not in d
+    assert d["rel_l2_vs_cpu_ref"] < 1e-10 and d["iters_match_cpu_ref"] is True
