@@ -372,3 +372,28 @@ def test_workgroup_wide_fom(hip, N):
         assert np.isfinite(ho).all() and ito.max() < 20
         assert rel_l2(h, ho) < TOL and np.array_equal(it, ito), f"N={N} graded={graded}"
         assert (fl == 0).all()
+
+
+def test_full_bench_workload_against_the_oracle(hip):
+    """The whole bench.py workload (BASELINE configs[1]: 1024 samples x N=1024 x 500 steps, dt=0.025, the
+    bench's seed) against the C oracle on the host cores: every one of the 512 000 Picard iteration counts
+    identical, worst per-sample rel-L2 of the full history <= 1e-10."""
+    from burgers_hip import fom, lib
+    rng = np.random.default_rng(20251121)
+    N, B, nsteps, dt = 1024, 1024, 500, 0.025
+    X, _ = mesh(N)
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    res = fom.fom_run(X, np.ones(N), mu1, mu2, dt, nsteps)
+    h = lib.to_host(res.hist)
+    it = res.iters.cpu().numpy()
+    fl = res.flags.cpu().numpy()
+    assert (fl & lib.BG_FLAG_NONFINITE == 0).all()
+    assert np.array_equal((fl & lib.BG_FLAG_HIT_CAP) != 0, (it >= 20).any(axis=1))   # cap exits are flagged, as in the oracle's counts
+    worst = 0.0
+    for b0 in range(0, B, 256):                              # oracle in four blocks: bounded host memory
+        ho, ito = bc.fom_run(X, np.ones(N), mu1[b0:b0 + 256], mu2[b0:b0 + 256], dt, nsteps)
+        assert np.array_equal(it[b0:b0 + 256], ito), f"iteration counts differ in block {b0}"
+        d = np.linalg.norm((h[b0:b0 + 256] - ho).reshape(256, -1), axis=1) / np.linalg.norm(ho.reshape(256, -1), axis=1)
+        worst = max(worst, float(d.max()))
+    assert worst < TOL, worst
+    assert int(it.sum()) == 8415010                          # the bench's newton_steps_per_pass
