@@ -368,7 +368,7 @@ const char* bg_strerror(int code)
     switch (code) {
         case BG_OK: return "ok";
         case BG_ERR_BAD_ARG: return "bad argument";
-        case BG_ERR_UNSUPPORTED_N: return "N not supported by the fused kernels (2 <= N <= 8192; FD stepper: N <= 2048)";
+        case BG_ERR_UNSUPPORTED_N: return "N not supported by the fused kernels (2 <= N <= 8192)";
         case BG_ERR_NONUNIFORM: return "mesh is not uniform";
         case BG_ERR_LAUNCH: return "kernel launch failed (see bg_last_hip_error)";
         case BG_ERR_UNSUPPORTED_R: return "reduced dimension not supported";

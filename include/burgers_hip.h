@@ -63,7 +63,8 @@ int bg_last_hip_error(void);
 
 /* Largest N of bg_fom_run / bg_fom_assemble / bg_tridiag_solve: 8192.  N <= 1536 runs one wavefront per
  * sample (rows per lane <= 24), 1536 < N <= 8192 one 256-thread workgroup per sample (rows per thread <= 32);
- * at 24 rows per lane and 32 per thread part of the state spills to AGPRs / scratch.  bg_fd_run: N <= 2048. */
+ * at 24 rows per lane and 32 per thread part of the state spills to AGPRs / scratch.  bg_fd_run switches to
+ * the workgroup form above N = 2048 (same limit, 8192). */
 int bg_fom_max_n(void);
 
 /* ---------------------------------------------------------------------------------
@@ -187,7 +188,7 @@ int bg_lu_solve_update(int n, int B, const double *A, const double *rhs, int mod
  *   reference: FD/fd_burgers.py:59-107 (time + Newton loops), residual :28-35, Jacobian :37-44,
  *   boundary values :19-22 (U[0] = mu1, U[-1] = U[-2]).  Central differences with the lagged
  *   artificial viscosity nu = 0.25 dx max|U|; stop on max|R| < tol or max|dU|/max|U| < tol.
- *   Arrays as in bg_fom_run; x must be the linspace(a, b, N) of the reference; N <= 2048.
+ *   Arrays as in bg_fom_run; x must be the linspace(a, b, N) of the reference; N <= 8192.
  *   iters[b][t] = Newton solves taken in step t; flags: BG_FLAG_HIT_CAP when max_it ran out.
  * ================================================================================= */
 int bg_fd_run(int N, int B, int nsteps, const double *x, const double *u0, const double *mu1,

@@ -147,8 +147,8 @@ def test_edge_cases(hip):
     # N beyond the workgroup-per-sample range is refused, not mis-computed
     with pytest.raises(lib.BurgersHipError):
         fom.fom_run(np.linspace(0, 100, 9000), np.ones(9000), 4.5, 0.02, 0.05, 1)
-    with pytest.raises(lib.BurgersHipError):              # the FD stepper stays wave-per-sample
-        fom.fd_run(0.0, 100.0, 2500, np.ones(2500), 4.5, 0.02, 0.01, 1)
+    with pytest.raises(lib.BurgersHipError):
+        fom.fd_run(0.0, 100.0, 9000, np.ones(9000), 4.5, 0.02, 0.01, 1)
     Xbad = X.copy(); Xbad[7] = Xbad[9]
     with pytest.raises(ValueError):                     # nodes must be strictly increasing
         fom.fom_run(Xbad, np.ones(256), 4.5, 0.02, 0.05, 1)
@@ -397,3 +397,18 @@ def test_full_bench_workload_against_the_oracle(hip):
         worst = max(worst, float(d.max()))
     assert worst < TOL, worst
     assert int(it.sum()) == 8415010                          # the bench's newton_steps_per_pass
+
+
+@pytest.mark.parametrize("N", [2049, 3072, 4100, 6144, 8192])
+def test_workgroup_wide_fd_stepper(hip, N):
+    """FD true-Newton stepper above N = 2048 (one workgroup per sample) against the oracle."""
+    from burgers_hip import fom
+    rng = np.random.default_rng(7000 + N)
+    B = 2
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    dt = 0.05 * 512 / N
+    res = fom.fd_run(0.0, 100.0, N, np.ones(N), mu1, mu2, dt, 5)
+    torch.cuda.synchronize()
+    for b in range(B):
+        Uo, ito = br.fd_newton(0.0, 100.0, N, dt, 5, np.ones(N), mu1[b], mu2[b], return_iters=True)
+        assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < TOL and np.array_equal(res.iters[b].cpu().numpy(), ito)
