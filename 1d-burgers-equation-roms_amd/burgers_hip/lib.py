@@ -30,6 +30,7 @@ BG_FLAG_HIT_CAP, BG_FLAG_NONFINITE = 1, 2
 BG_OPT_SUPG, BG_OPT_NONUNIFORM, BG_OPT_W_COLMAJOR = 1, 2, 4
 BG_ACT_NONE, BG_ACT_ELU, BG_ACT_RELU, BG_ACT_TANH = 0, 1, 2, 3
 BG_COUNTER_SLOTS, BG_COUNTER_STRIDE = 16, 32
+BG_RBF_GAUSSIAN, BG_RBF_IMQ = 0, 1
 
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -83,6 +84,8 @@ _SIGNATURES = {
                                    c_int_p, c_double_p, c_int_p, ctypes.c_void_p]),
     "bg_jacobi_sweep": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_int_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_double, c_int_p, ctypes.c_void_p]),
+    "bg_rbf_eval": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p,
+                                   c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_void_p]),
     "bg_mlp_act_jvp": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
 }

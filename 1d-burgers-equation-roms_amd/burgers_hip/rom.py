@@ -623,44 +623,57 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
 
 # ----------------------------------------------------------------------- POD-RBF
 class RbfClosure:
-    """Scaled RBF closure q_s = unscale(k(|x - x_i|) @ W), x = scale(q_p), and its full-chain
-    Jacobian, batched over samples (FEM/fem_burgers.py:160-260): plain dense contractions."""
+    """Scaled RBF closure q_s = unscale(k(|x - x_i|) @ W), x = scale(q_p), and its full-chain Jacobian, batched
+    over samples (FEM/fem_burgers.py:160-260).  bg_rbf_eval produces the kernel values phi (B, Ns) and the
+    gradient factors d phi / d q_p already transposed, GT (B, n, Ns), in one pass; value and Jacobian are then
+    ONE GEMM each against the output-scaled weights: q_s = phi Wd + (dy/2 + y_min), (dq_s/dq_p)^T = GT Wd."""
 
     def __init__(self, X_train, W, eps, kernel, x_min, x_max, y_min, y_max, device):
         if kernel not in ("gaussian", "imq"):
             raise ValueError("kernel must be 'gaussian' or 'imq'.")
         f = lambda a: _as_dev(np.asarray(a, dtype=np.float64), device)
-        self.Xt, self.W, self.eps, self.kernel = f(X_train), f(W), float(eps), kernel
-        self.x_min, self.y_min = f(x_min), f(y_min)
+        self.L = _lib.load()
+        self.device = device
+        Xt, Wm = f(X_train), f(W)
+        self.eps = float(eps)
+        self.kind = _lib.BG_RBF_GAUSSIAN if kernel == "gaussian" else _lib.BG_RBF_IMQ
+        self.x_min, y_min = f(x_min), f(y_min)
         self.dx = f(x_max) - self.x_min
         self.dx[self.dx < 1e-15] = 1.0
-        self.dy = f(y_max) - self.y_min
-        self.dy[self.dy < 1e-15] = 1.0
-        if self.W.shape != (self.Xt.shape[0], self.dy.numel()) or self.Xt.shape[1] != self.dx.numel():
+        dy = f(y_max) - y_min
+        dy[dy < 1e-15] = 1.0
+        if Wm.shape != (Xt.shape[0], dy.numel()) or Xt.shape[1] != self.dx.numel():
             raise ValueError("X_train must be (Ns, n) and W (Ns, nbar)")
+        self.Ns, self.n = Xt.shape
+        self.XtT = Xt.t().contiguous()                                 # (n, Ns): centre index fastest
+        self.Wd = (Wm * (0.5 * dy)).contiguous()                       # output scaling folded into the weights
+        self.bias = (0.5 * dy + y_min).contiguous()
+        self._buf = {}
 
-    def _diff_r2(self, qp):
-        xs = 2.0 * ((qp - self.x_min) / self.dx) - 1.0                # (B, n)
-        diff = xs.unsqueeze(1) - self.Xt.unsqueeze(0)                  # (B, Ns, n)
-        return diff, (diff * diff).sum(-1)
+    def _eval(self, qp, want_gt):
+        B = qp.shape[0]
+        if B not in self._buf:
+            f64 = dict(dtype=torch.float64, device=self.device)
+            self._buf[B] = (torch.empty((B, self.Ns), **f64), torch.empty((B, self.n, self.Ns), **f64))
+        phi, GT = self._buf[B]
+        qp = qp.contiguous()
+        with torch.cuda.device(self.device):
+            rc = self.L.bg_rbf_eval(B, self.n, self.Ns, self.kind, self.eps, _lib.ptr(qp), _lib.ptr(self.x_min),
+                                    _lib.ptr(self.dx), _lib.ptr(self.XtT), _lib.ptr(phi),
+                                    _lib.ptr(GT) if want_gt else None, _lib.stream_ptr(self.device))
+        _lib.check(rc, "bg_rbf_eval")
+        return phi, GT
 
     def value(self, qp):
-        _, r2 = self._diff_r2(qp)
-        r = torch.sqrt(r2)
-        k = torch.exp(-(self.eps * r) ** 2) if self.kernel == "gaussian" else 1.0 / torch.sqrt(1.0 + (self.eps * r) ** 2)
-        return 0.5 * (k @ self.W + 1.0) * self.dy + self.y_min         # (B, nbar)
+        phi, _ = self._eval(qp, False)
+        return torch.addmm(self.bias, phi, self.Wd)                    # (B, nbar)
+
+    def jacobian_t(self, qp):
+        _, GT = self._eval(qp, True)
+        return torch.matmul(GT, self.Wd)                               # (B, n, nbar): one GEMM over B n rows
 
     def jacobian(self, qp):
-        diff, r2 = self._diff_r2(qp)
-        r = torch.sqrt(r2)
-        if self.kernel == "gaussian":
-            G = (-2.0 * self.eps ** 2) * (torch.exp(-(self.eps * r) ** 2).unsqueeze(-1) * diff)
-        else:
-            k = (1.0 + (self.eps ** 2) * (r ** 2)) ** (-0.5)
-            G = (-(self.eps ** 2)) * ((k ** 3).unsqueeze(-1) * diff)
-        # J^T as ONE GEMM over B n rows: (B, n, Ns) . (Ns, nbar); the broadcast form W^T . G is B small GEMMs
-        JT = torch.matmul(G.transpose(1, 2), self.W) * (2.0 / self.dx).reshape(1, -1, 1)
-        return ((0.5 * self.dy).reshape(1, 1, -1) * JT).transpose(1, 2)         # (B, nbar, n) view
+        return self.jacobian_t(qp).transpose(1, 2)                     # (B, nbar, n) view
 
 
 def pod_rbf_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, X_train, W, epsilon, x_min, x_max, y_min, y_max,
@@ -686,7 +699,8 @@ def pod_rbf_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, X_train, W, epsilon, x_mi
         st.begin_step()
         while True:
             qp = (U0 @ Up).contiguous()                                     # q_p = U_p^T U0        (:1352)
-            rom_reduce(c, tangent(rbf.jacobian(qp)), U0, G, proj, True, st.active, Ar, br, None, colmajor=True)   # (:1361)
+            tangent.jt.copy_(rbf.jacobian_t(qp))
+            rom_reduce(c, tangent.gemm(), U0, G, proj, True, st.active, Ar, br, None, colmajor=True)   # (:1361)
             left = st.solve_update(1, Ar, br, qp, q, tol_newton, max_newton)   # q_new = q_p + dq, err = |dq|/|q_new|
             act = st.active_before
             U1 = q @ UpT + rbf.value(q) @ UsT                               # (:1378-1381)

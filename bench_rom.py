@@ -54,7 +54,8 @@ def timed(fn):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", nargs="*", default=["pod_galerkin", "pod_lspg", "quadratic", "ann"])
+    ap.add_argument("--which", nargs="*", default=["pod_galerkin", "pod_lspg", "quadratic", "ann"],
+                    help="also available: rbf (POD-RBF closure of tests/golden/rbf_n17.npz, SURVEY 8f.3)")
     ap.add_argument("--time-steps", type=int, default=40)
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--r", type=int, default=40)
@@ -125,6 +126,17 @@ def main():
             ann_flops = 2 * 132000 * (1 + n) + 2 * N * (n + nb) * (1 + n) + 2 * N * n * n + 11 * N * n
             report(f"configs[4]: POD-ANN n={n}, nbar={nb} (fp32 MLP), {B} samples/GPU, N={N}", B, res, secs, ann_flops,
                    {"r": n})
+        elif which == "rbf":
+            g = np.load(os.path.join(REPO, "tests", "golden", "rbf_n17.npz"))
+            B = args.batch_ann
+            m1, m2 = mus(B)
+            cl = (g["U_p"], g["U_s"], g["X_train"], g["W_gaussian"], float(g["eps_gaussian"]), g["x_min"], g["x_max"],
+                  g["y_min"], g["y_max"])
+            rom.pod_rbf_run(X, np.ones(N), m1[:32], m2[:32], dt, 2, *cl)
+            res, secs = timed(lambda: rom.pod_rbf_run(X, np.ones(N), m1, m2, dt, nT, *cl))
+            n, nb, ns = g["U_p"].shape[1], g["U_s"].shape[1], g["X_train"].shape[0]
+            rbf_flops = 2 * ns * (n + nb) * (1 + n) + 2 * N * (n + nb) * (1 + n) + 2 * N * n * n + 11 * N * n
+            report(f"POD-RBF (gaussian, {ns} centres) n={n}, nbar={nb}, {B} samples/GPU, N={N}", B, res, secs, rbf_flops, {"r": n})
 
 
 if __name__ == "__main__":

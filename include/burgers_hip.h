@@ -56,6 +56,9 @@ enum { BG_FLAG_HIT_CAP = 1, BG_FLAG_NONFINITE = 2 };
 /* activation kinds of bg_mlp_act_jvp */
 enum { BG_ACT_NONE = 0, BG_ACT_ELU = 1, BG_ACT_RELU = 2, BG_ACT_TANH = 3 };
 
+/* kernels of bg_rbf_eval */
+enum { BG_RBF_GAUSSIAN = 0, BG_RBF_IMQ = 1 };
+
 int bg_abi_version(void);
 const char *bg_strerror(int code);
 /* hipError_t of the most recent failed launch on the calling thread (0 if none). */
@@ -234,6 +237,16 @@ int bg_mlp_act_jvp(int B, int n1, int h, float *z, const float *bias, int act, f
  * singular vectors (as rows), J its right singular vectors (as rows). */
 int bg_jacobi_sweep(int m, int ld, double *G, double *J, const int32_t *pairs, int n_steps, int n_pairs,
                     double tol, int32_t *rotations, void *stream);
+
+/* bg_rbf_eval -- kernel values and gradient factors of the scaled RBF closure of pod_rbf_prom
+ *   reference: FEM/fem_burgers.py:160-260 (scaled gaussian / inverse-multiquadric closure and its Jacobian).
+ *   qp [B][n] reduced coordinates; x_min, dx [n] input scaling (xs = 2 (qp - x_min)/dx - 1);
+ *   XtT [n][Ns] training centres, transposed;  eps shape parameter
+ *   phi [B][Ns]     <- k(|xs - Xt_i|)                                            (NULL = skip)
+ *   GT  [B][n][Ns]  <- d phi_i / d qp_k  (chain rule through the input scaling included) (NULL = skip)
+ * The closure value and Jacobian follow as phi . W and GT . W (one GEMM each). */
+int bg_rbf_eval(int B, int n, int Ns, int kind, double eps, const double *qp, const double *x_min,
+                const double *dx, const double *XtT, double *phi, double *GT, void *stream);
 
 #ifdef __cplusplus
 }

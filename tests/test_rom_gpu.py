@@ -534,3 +534,23 @@ def test_jacobi_svd_core(hip, m):
     assert np.abs(s - s0).max() / s0[0] < 1e-13 and np.abs(s / s0 - 1).max() < 1e-5    # A itself carries eps*sigma_1
     assert np.abs(U.T @ U - np.eye(m)).max() < 1e-13 and np.abs(Vh @ Vh.T - np.eye(m)).max() < 1e-13
     assert np.abs((U * s) @ Vh - A).max() < 1e-13
+
+
+def test_rbf_closure_kernel(hip):
+    """bg_rbf_eval + the two GEMMs against the closure value / Jacobian recorded from the reference
+    (FEM/fem_burgers.py:160-260) and against the oracle on a random batch, both kernels."""
+    from burgers_hip import rom
+    g = load_golden("rbf_n17.npz")
+    rng = np.random.default_rng(5)
+    for kernel in ("gaussian", "imq"):
+        args = (g["X_train"], g["W_" + kernel], float(g["eps_" + kernel]), kernel, g["x_min"], g["x_max"], g["y_min"], g["y_max"])
+        cl = rom.RbfClosure(*args, torch.device("cuda", 0))
+        qp = np.vstack([g["qp_" + kernel], g["qp_" + kernel] + 0.05 * rng.standard_normal((6, g["qp_" + kernel].size))])
+        val = cl.value(_dev(qp)).cpu().numpy()
+        jac = cl.jacobian(_dev(qp)).cpu().numpy()
+        assert np.abs(val[0] - g["val_" + kernel]).max() < 1e-11 * max(1.0, np.abs(g["val_" + kernel]).max())
+        assert np.abs(jac[0] - g["jac_" + kernel]).max() < 1e-10 * np.abs(g["jac_" + kernel]).max()
+        for b in range(1, 7):
+            assert np.abs(val[b] - br.rbf_value(qp[b], *args)).max() < 1e-11 * max(1.0, np.abs(val[b]).max())
+            jo = br.rbf_jacobian(qp[b], *args)
+            assert np.abs(jac[b] - jo).max() < 1e-10 * np.abs(jo).max()
