@@ -737,6 +737,8 @@ def local_prom_run(X, u0, mu1, mu2, dt, nsteps, centers, local_bases, U_global, 
     cen = _as_dev(centers, c.device)                                        # (n_clusters, m)
     Ug = _as_dev(U_global, c.device)[:, :num_global_modes].contiguous()
     col = torch.arange(rmax, device=c.device)
+    stackT = stack.transpose(1, 2).contiguous()                              # (C, rmax, N)
+    rows = torch.arange(c.B, device=c.device)
     hist, iters, flags = _alloc_hist(c, nsteps)
     Ar, br, wtu, G = _workspace(c, rmax)
     st = _IterState(c, rmax)
@@ -757,7 +759,9 @@ def local_prom_run(X, u0, mu1, mu2, dt, nsteps, centers, local_bases, U_global, 
             Ar.diagonal(dim1=1, dim2=2).add_(pad * st.active[:, None].to(torch.float64))
             left = st.solve_update(1, Ar, br, wtu, q, tol, max_it)           # q = Phi^T U0 + dq
             act = st.active_before
-            U1 = torch.bmm(W, q.unsqueeze(-1)).squeeze(-1)                   # U1 = Phi q
+            # U1 = Phi q: one GEMM per cluster over the whole batch against the SHARED bases, then each sample
+            # picks its cluster's row (a bmm against the gathered per-sample copies streams B N r doubles)
+            U1 = torch.matmul(q, stackT)[slot, rows]                         # (C, B, N) -> (B, N)
             U0 = torch.where(act[:, None], U1, U0).contiguous()
             if left == 0:
                 break

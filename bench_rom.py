@@ -55,7 +55,8 @@ def timed(fn):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", nargs="*", default=["pod_galerkin", "pod_lspg", "quadratic", "ann"],
-                    help="also available: rbf (POD-RBF closure of tests/golden/rbf_n17.npz, SURVEY 8f.3)")
+                    help="also available: rbf (POD-RBF closure of tests/golden/rbf_n17.npz, SURVEY 8f.3), "
+                         "local (local POD bases of tests/golden/local_pod.npz, SURVEY 8f.2)")
     ap.add_argument("--time-steps", type=int, default=40)
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--r", type=int, default=40)
@@ -126,6 +127,17 @@ def main():
             ann_flops = 2 * 132000 * (1 + n) + 2 * N * (n + nb) * (1 + n) + 2 * N * n * n + 11 * N * n
             report(f"configs[4]: POD-ANN n={n}, nbar={nb} (fp32 MLP), {B} samples/GPU, N={N}", B, res, secs, ann_flops,
                    {"r": n})
+        elif which == "local":
+            g = np.load(os.path.join(REPO, "tests", "golden", "local_pod.npz"))
+            B = args.batch_pod
+            m1, m2 = mus(B)
+            bases = {c: g[f"basis{c}"] for c in range(4)}
+            cl = (g["centers"], bases, g["U_global"], 12)
+            rom.local_prom_run(X, np.ones(N), m1[:32], m2[:32], dt, 2, *cl, projection="LSPG")
+            res, secs = timed(lambda: rom.local_prom_run(X, np.ones(N), m1, m2, dt, nT, *cl, projection="LSPG"))
+            rl = max(b.shape[1] for b in bases.values())
+            report(f"local POD-LSPG, 4 clusters, widths 14..30, {B} samples/GPU, N={N}", B, res, secs,
+                   2 * N * rl * rl + 11 * N * rl + (2 * rl ** 3) / 3, {"r": rl})
         elif which == "rbf":
             g = np.load(os.path.join(REPO, "tests", "golden", "rbf_n17.npz"))
             B = args.batch_ann
