@@ -63,6 +63,10 @@ _SIGNATURES = {
                                      c_double_p, ctypes.c_longlong, c_double_p, c_double_p, c_double_p,
                                      c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_int_p,
                                      c_double_p, c_double_p, c_double_p, ctypes.c_void_p]),
+    "bg_rom_reduce_indexed": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
+                                             c_double_p, ctypes.c_longlong, c_int_p, c_double_p, c_double_p, c_double_p,
+                                             c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_int_p,
+                                             c_double_p, c_double_p, c_double_p, ctypes.c_void_p]),
     "bg_rom_reduce_lifted": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
                                             c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                             c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_int_p,

@@ -81,14 +81,24 @@ def _mass_rhs(c, Un, out):
     return out
 
 
-def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None, colmajor=False):
+def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None, colmajor=False, w_index=None):
     """Ar, br (and optionally W^T u) of every active sample.  W: (N, r) shared or (B, N, r);
-    with ``colmajor`` the transposed blocks (r, N) / (B, r, N)."""
+    with ``colmajor`` the transposed blocks (r, N) / (B, r, N); with ``w_index`` (B,) int32 a stack
+    (C, N, r) of bases of which sample b uses block w_index[b]."""
     r = W.shape[-2] if colmajor else W.shape[-1]
     if r > c.L.bg_rom_max_r() or c.N > c.L.bg_rom_max_n():
-        return _rom_reduce_library(c, W.transpose(-1, -2) if colmajor else W, U, proj, supg, active, Ar, br, wtu)
+        Wl = W if w_index is None else W[w_index.long()]
+        return _rom_reduce_library(c, Wl.transpose(-1, -2) if colmajor else Wl, U, proj, supg, active, Ar, br, wtu)
     stride = 0 if W.dim() == 2 else c.N * r
     opts = (1 if supg else 0) | c.mesh_opt | (_lib.BG_OPT_W_COLMAJOR if colmajor else 0)
+    if w_index is not None:
+        with torch.cuda.device(c.device):
+            rc = c.L.bg_rom_reduce_indexed(c.N, c.B, r, proj, _lib.ptr(c.X), _lib.ptr(W), stride, _lib.ptr(w_index),
+                                           _lib.ptr(U), _lib.ptr(G), _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, opts,
+                                           _lib.ptr(active) if active is not None else None, _lib.ptr(Ar), _lib.ptr(br),
+                                           _lib.ptr(wtu) if wtu is not None else None, c.stream())
+        _lib.check(rc, "bg_rom_reduce_indexed")
+        return
     with torch.cuda.device(c.device):
         rc = c.L.bg_rom_reduce(c.N, c.B, r, proj, _lib.ptr(c.X), _lib.ptr(W), stride, _lib.ptr(U), _lib.ptr(G),
                                _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, opts,
@@ -751,11 +761,11 @@ def local_prom_run(X, u0, mu1, mu2, dt, nsteps, centers, local_bases, U_global, 
         slot = slot_of[cid]
         if bool((slot < 0).any()):
             raise KeyError("a predicted cluster has no local basis")
-        W = stack[slot].contiguous()                                          # (B, N, rmax)     (:1013)
+        slot32 = slot.to(torch.int32)                                         # basis of each sample (:1013)
         pad = (col[None, :] >= width_t[slot][:, None]).to(torch.float64)      # 1 on padded reduced unknowns
         st.begin_step()
         while True:
-            rom_reduce(c, W, U0, G, proj, True, st.active, Ar, br, wtu)
+            rom_reduce(c, stack, U0, G, proj, True, st.active, Ar, br, wtu, w_index=slot32)
             Ar.diagonal(dim1=1, dim2=2).add_(pad * st.active[:, None].to(torch.float64))
             left = st.solve_update(1, Ar, br, wtu, q, tol, max_it)           # q = Phi^T U0 + dq
             act = st.active_before

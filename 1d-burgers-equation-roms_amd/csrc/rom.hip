@@ -121,6 +121,7 @@ struct ReduceArgs {
     int N, B, r, proj, supg, lift_only, nonuniform;
     int w_frag;              // 1: W is in the fragment-major layout of bg_quad_tangent (rom_reduce4 only)
     int w_colmajor;          // 1: W is [r][N] per sample (BG_OPT_W_COLMAJOR)
+    const int32_t* w_index;  // [B] or null: sample b uses block w_index[b] of W (blocks w_stride apart)
 };
 
 template <int S, int NT, int PROJ>
@@ -142,12 +143,15 @@ __global__ __launch_bounds__(256, 1) void rom_reduce_kernel(ReduceArgs a)
 
     double frag[NT][S + 2];                 // W[rowbase + s - 1][16 t + c], s = 0..S+1
     bool have_frags = false;
+    int last_block = -1;
 
     for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
         if (a.active && a.active[smp] == 0) continue;        // workgroup-uniform
-        // ---- basis / tangent fragments --------------------------------------------------
-        if (a.w_stride != 0 || !have_frags) {
-            const double* Wp = a.W + (size_t)smp * (size_t)a.w_stride;
+        // ---- basis / tangent fragments (kept across samples while the block of W stays the same) -------
+        const int wblock = a.w_stride == 0 ? 0 : (a.w_index ? a.w_index[smp] : smp);
+        if (!have_frags || wblock != last_block) {
+            last_block = wblock;
+            const double* Wp = a.W + (size_t)wblock * (size_t)a.w_stride;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = 16 * t + c;
@@ -391,10 +395,13 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
     int buf = 0;
     if (pref && smp < a.B) prefetch(smp, 0);
 
+    int last_block = -1;
     while (smp < a.B) {
         const int nxt = next_active(smp + gridDim.x);
-        if (a.w_stride != 0 || !have_frags) {
-            const double* Wp = a.W + (size_t)smp * (size_t)a.w_stride;
+        const int wblock = a.w_stride == 0 ? 0 : (a.w_index ? a.w_index[smp] : smp);
+        if (!have_frags || wblock != last_block) {     // fragments stay in registers while the block of W stays the same
+            last_block = wblock;
+            const double* Wp = a.W + (size_t)wblock * (size_t)a.w_stride;
             if (a.w_frag) {
                 // fragment-major: element (row o*S + s, col 4c + t) at ((c*S + s)*64 + o)*4 + t:
                 // every (c, s) is one coalesced 2 KB read for the workgroup; halos come from owners o -+ 1
@@ -807,7 +814,7 @@ int bg_rom_max_r(void) { return 47; }
 static int rom_reduce_impl(int N, int B, int r, int projection, const double* x, const double* W, long long w_stride,
                            const double* U, const double* G, const double* hfs, const double* mu1, double dt, double E,
                            int supg, const int32_t* active, double* Ar, double* br, double* wtu, const double* q_in,
-                           double* Uout, int lift_only, void* stream, int w_frag = 0)
+                           double* Uout, int lift_only, void* stream, int w_frag = 0, const int32_t* w_index = nullptr)
 {
     if (N < 2 || B < 0 || r < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
     if (projection != BG_PROJ_GALERKIN && projection != BG_PROJ_LSPG) return BG_ERR_PROJECTION;
@@ -823,6 +830,7 @@ static int rom_reduce_impl(int N, int B, int r, int projection, const double* x,
     a.supg = supg & BG_OPT_SUPG; a.nonuniform = (supg & BG_OPT_NONUNIFORM) ? 1 : 0;
     a.q_in = q_in; a.Uout = Uout; a.lift_only = lift_only; a.w_frag = w_frag;
     a.w_colmajor = (supg & BG_OPT_W_COLMAJOR) ? 1 : 0;
+    a.w_index = w_index;
     if (w_frag && (r > 40 || getenv("BG_ROM_FORCE_16X16"))) return BG_ERR_UNSUPPORTED_R;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -892,6 +900,16 @@ int bg_rom_reduce(int N, int B, int r, int projection, const double* x, const do
 {
     return rom_reduce_impl(N, B, r, projection, x, W, w_stride, U, G, hfs, mu1, dt, E, supg, active, Ar, br, wtu,
                            nullptr, nullptr, 0, stream);
+}
+
+int bg_rom_reduce_indexed(int N, int B, int r, int projection, const double* x, const double* W, long long w_stride,
+                          const int32_t* w_index, const double* U, const double* G, const double* hfs, const double* mu1,
+                          double dt, double E, int supg, const int32_t* active, double* Ar, double* br, double* wtu,
+                          void* stream)
+{
+    if (B > 0 && (!w_index || w_stride == 0)) return BG_ERR_BAD_ARG;
+    return rom_reduce_impl(N, B, r, projection, x, W, w_stride, U, G, hfs, mu1, dt, E, supg, active, Ar, br, wtu,
+                           nullptr, nullptr, 0, stream, 0, w_index);
 }
 
 int bg_rom_reduce_lifted(int N, int B, int r, int projection, const double* x, const double* Phi, const double* q,

@@ -153,6 +153,15 @@ int bg_rom_reduce(int N, int B, int r, int projection, const double *x, const do
                   const double *mu1, double dt, double E, int supg, const int32_t *active,
                   double *Ar, double *br, double *wtu, void *stream);
 
+/* bg_rom_reduce_indexed -- bg_rom_reduce with a small set of bases shared among the samples: sample b
+ * uses the block W + w_index[b] * w_stride (local POD: the basis of its cluster; reference
+ * local_prom_burgers, FEM/fem_burgers.py:1011-1013).  A workgroup keeps the fragments in registers
+ * while consecutive samples of its stride use the same block. */
+int bg_rom_reduce_indexed(int N, int B, int r, int projection, const double *x, const double *W,
+                          long long w_stride, const int32_t *w_index, const double *U, const double *G,
+                          const double *hfs, const double *mu1, double dt, double E, int supg,
+                          const int32_t *active, double *Ar, double *br, double *wtu, void *stream);
+
 /* bg_lu_solve -- x[b] = solve(A[b], sign * rhs[b]), partial pivoting, n <= 64
  *   reference: np.linalg.solve(Ar, -br) at FEM/fem_burgers.py:767 / :1161 / :1237
  *   (LAPACK gesv).  info[b] = 0, or k+1 when the pivot of step k is exactly zero
