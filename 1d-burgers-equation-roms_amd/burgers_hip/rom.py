@@ -194,10 +194,7 @@ class _IterState:
     def _solve_update_library(self, mode, Ar, br, wtu, q, tol, max_it):
         """bg_lu_solve_update for n > 64: rocSOLVER LU through torch, same update rules."""
         act = self.active.bool()
-        try:
-            dq = torch.linalg.solve(Ar, -br)
-        except RuntimeError as e:
-            raise SingularReducedSystem("Singular matrix") from e
+        dq = _batched_solve(Ar, -br, act)
         qn = (wtu if mode == 1 else q) + dq
         q.copy_(torch.where(act[:, None], qn, q))
         nd, nq = torch.linalg.vector_norm(dq, dim=1), torch.linalg.vector_norm(qn, dim=1)
@@ -298,6 +295,26 @@ def pod_prom_run(X, u0, mu1, mu2, dt, nsteps, Phi, projection="Galerkin", E=0.0,
     return FomResult(hist, iters, flags)
 
 
+def _batched_solve(A, b, considered):
+    """x = solve(A, b) over a batch (rocSOLVER LU).  Like numpy (:767), an exactly singular FINITE system of a
+    sample that is still iterating raises; a system that already holds NaN/Inf (a diverged sample) does not --
+    its solution is simply non-finite, which the caller flags -- and neither does a sample that is masked out.
+    The batch goes through in chunks: hipblasDgetrfBatched fails to allocate its workspace beyond about
+    n^2 * batch = 1e7 (n = 160: 256 systems pass, 512 do not; tools/probe_solve.py)."""
+    B, n, _ = A.shape
+    chunk = max(16, int(6.0e6 / (n * n)))
+    x = torch.empty_like(b)
+    info = torch.empty((B,), dtype=torch.int32, device=A.device)
+    for b0 in range(0, B, chunk):
+        xs, inf = torch.linalg.solve_ex(A[b0:b0 + chunk], b[b0:b0 + chunk], check_errors=False)
+        x[b0:b0 + chunk] = xs
+        info[b0:b0 + chunk] = inf
+    bad = (info != 0) & considered & torch.isfinite(A).all(dim=2).all(dim=1)
+    if bool(bad.any()):
+        raise SingularReducedSystem("Singular matrix")
+    return x
+
+
 def _pod_prom_run_library(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E, tol, max_it, device):
     """POD PROM for bases beyond the register-resident MFMA kernels (r > 47 or N > 512; the thesis
     also runs r = 96, 160, 227): bg_fom_assemble (HIP) for A(u), R(u), then the projection and
@@ -312,8 +329,8 @@ def _pod_prom_run_library(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E, tol, max_it
         raise ValueError("Phi must have one row per mesh node")
     PhiT = Phid.t().contiguous()
     zrow = torch.zeros((1, Phid.shape[1]), dtype=torch.float64, device=c.device)
-    Phi_dn = torch.cat([zrow, Phid[:-1]], 0)              # row i holds Phi[i-1]
-    Phi_up = torch.cat([Phid[1:], zrow], 0)               # row i holds Phi[i+1]
+    PhiT_dn = torch.cat([zrow, Phid[:-1]], 0).t().contiguous()     # column i holds Phi[i-1]
+    PhiT_up = torch.cat([Phid[1:], zrow], 0).t().contiguous()      # column i holds Phi[i+1]
     hist, iters, flags = _alloc_hist(c, nsteps)
     U0 = c.u0.clone()
     for n in range(nsteps):
@@ -322,17 +339,15 @@ def _pod_prom_run_library(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E, tol, max_it
         k = torch.zeros((c.B,), dtype=torch.int32, device=c.device)
         while True:
             lo, di, up, rhs = _fom.fom_assemble(Xh, U0, Un, c.mu1, c.mu2, c.dt, E=c.E, supg=True, device=c.device)
-            Y = di.unsqueeze(-1) * Phid + lo.unsqueeze(-1) * Phi_dn + up.unsqueeze(-1) * Phi_up     # A Phi, (B, N, r)
+            # (A Phi)^T as (B, r, N): the Galerkin projection is then ONE GEMM over B r rows against Phi
+            YT = di.unsqueeze(1) * PhiT + lo.unsqueeze(1) * PhiT_dn + up.unsqueeze(1) * PhiT_up
             if proj == _lib.BG_PROJ_GALERKIN:
-                Ar = torch.matmul(PhiT, Y)                                   # Phi^T A Phi       (:756)
+                Ar = torch.matmul(YT, Phid).transpose(1, 2)                  # Phi^T A Phi       (:756)
                 br = -(rhs @ Phid)                                           # Phi^T R, R = -rhs (:757)
             else:
-                Ar = torch.matmul(Y.transpose(1, 2), Y)                      # (A Phi)^T (A Phi) (:761)
-                br = -torch.matmul(Y.transpose(1, 2), rhs.unsqueeze(-1)).squeeze(-1)
-            try:
-                dq = torch.linalg.solve(Ar, -br)
-            except RuntimeError as e:                                       # numpy raises LinAlgError here (:767)
-                raise SingularReducedSystem("Singular matrix") from e
+                Ar = torch.matmul(YT, YT.transpose(1, 2))                    # (A Phi)^T (A Phi) (:761)
+                br = -torch.matmul(YT, rhs.unsqueeze(-1)).squeeze(-1)
+            dq = _batched_solve(Ar, -br, active)                            # np.linalg.solve (:767)
             q = U0 @ Phid + dq
             U1 = q @ PhiT
             err = torch.linalg.vector_norm(dq, dim=1) / torch.linalg.vector_norm(q, dim=1)
