@@ -36,6 +36,24 @@ def _as_dev(a, device, shape=None):
     return t.contiguous()
 
 
+def batch_inputs(u0, mu1, mu2, N, device):
+    """Broadcast u0 (N,) | (B, N), mu1 and mu2 scalar | (B,) to one batch size B.  Returns contiguous device
+    tensors u0 (B, N), mu1 (B,), mu2 (B,).  Sizes other than 1 and B are an error, not a silent broadcast."""
+    mu1d = _as_dev(mu1, device).reshape(-1)
+    mu2d = _as_dev(mu2, device).reshape(-1)
+    u0d = _as_dev(u0, device)
+    if u0d.dim() == 1:
+        u0d = u0d.unsqueeze(0)
+    if u0d.dim() != 2 or u0d.shape[-1] != N:
+        raise ValueError(f"u0 has {u0d.shape[-1]} entries per sample, mesh has {N}")
+    sizes = {"mu1": mu1d.numel(), "mu2": mu2d.numel(), "u0": u0d.shape[0]}
+    B = max(sizes.values()) if min(sizes.values()) > 0 else 0
+    for name, k in sizes.items():
+        if k not in (1, B):
+            raise ValueError(f"batch sizes do not agree: {sizes}")
+    return u0d.expand(B, N).contiguous(), mu1d.expand(B).contiguous(), mu2d.expand(B).contiguous()
+
+
 def check_mesh(X):
     """Validate the mesh and return it as host data (X is host data in the reference too)."""
     Xh = X.detach().cpu().numpy() if isinstance(X, torch.Tensor) else np.asarray(X, dtype=np.float64)
@@ -59,17 +77,8 @@ def fom_run(X, u0, mu1, mu2, dt, nsteps, E=0.0, tol=1e-6, max_it=20, supg=True, 
         options = _lib.mesh_options(check_mesh(X), supg) if validate_mesh else (_lib.BG_OPT_SUPG if supg else 0)
     Xd = _as_dev(X, device)
     N = Xd.numel()
-    mu1d = _as_dev(mu1, device).reshape(-1)
-    mu2d = _as_dev(mu2, device).reshape(-1)
-    B = max(mu1d.numel(), mu2d.numel())
-    mu1d = mu1d.expand(B).contiguous()
-    mu2d = mu2d.expand(B).contiguous()
-    u0d = _as_dev(u0, device)
-    if u0d.dim() == 1:
-        u0d = u0d.unsqueeze(0)
-    if u0d.shape[-1] != N:
-        raise ValueError(f"u0 has {u0d.shape[-1]} entries per sample, mesh has {N}")
-    u0d = u0d.expand(B, N).contiguous()
+    u0d, mu1d, mu2d = batch_inputs(u0, mu1, mu2, N, device)
+    B = mu1d.numel()
     if out is None:
         hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
         iters = torch.empty((B, nsteps), dtype=torch.int32, device=device)
@@ -137,16 +146,11 @@ def fd_run(a, b, N, u0, mu1, mu2, dt, nsteps, max_iter=30, tol=1e-8, device=None
     L = _lib.load()
     device = _lib.require_device(device)
     Xd = _as_dev(np.linspace(a, b, N), device)
-    mu1d = _as_dev(mu1, device).reshape(-1)
-    mu2d = _as_dev(mu2, device).reshape(-1)
-    B = max(mu1d.numel(), mu2d.numel())
-    mu1d, mu2d = mu1d.expand(B).contiguous(), mu2d.expand(B).contiguous()
-    u0d = _as_dev(u0, device)
-    if u0d.dim() == 1:
-        u0d = u0d.unsqueeze(0)
-    if u0d.shape[-1] != N:
-        raise ValueError(f"U0 has {u0d.shape[-1]} entries per sample, mesh has {N}")
-    u0d = u0d.expand(B, N).contiguous()
+    try:
+        u0d, mu1d, mu2d = batch_inputs(u0, mu1, mu2, N, device)
+    except ValueError as e:
+        raise ValueError(str(e).replace("u0 has", "U0 has")) from None
+    B = mu1d.numel()
     hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
     iters = torch.empty((B, nsteps), dtype=torch.int32, device=device)
     flags = torch.empty((B,), dtype=torch.int32, device=device)

@@ -19,6 +19,7 @@ import torch
 
 from . import lib as _lib
 from .fom import FomResult, _as_dev, check_mesh
+from .fom import batch_inputs as _batch_inputs
 
 PROJ = {"galerkin": _lib.BG_PROJ_GALERKIN, "lspg": _lib.BG_PROJ_LSPG}
 
@@ -57,14 +58,8 @@ def _setup(X, u0, mu1, mu2, dt, E, device, max_n=None):
     max_n = L.bg_fom_max_n() if max_n is None else max_n
     if N > max_n:
         raise NotImplementedError(f"ROM steppers cover N <= {max_n} (got {N})")
-    mu1d = _as_dev(mu1, device).reshape(-1)
-    mu2d = _as_dev(mu2, device).reshape(-1)
-    B = max(mu1d.numel(), mu2d.numel())
-    mu1d, mu2d = mu1d.expand(B).contiguous(), mu2d.expand(B).contiguous()
-    u0d = _as_dev(u0, device)
-    if u0d.dim() == 1:
-        u0d = u0d.unsqueeze(0)
-    u0d = u0d.expand(B, N).contiguous()
+    u0d, mu1d, mu2d = _batch_inputs(u0, mu1, mu2, N, device)
+    B = mu1d.numel()
     fdt = torch.empty((B, N), dtype=torch.float64, device=device)
     hfs = torch.empty((B, N), dtype=torch.float64, device=device)
     with torch.cuda.device(device):

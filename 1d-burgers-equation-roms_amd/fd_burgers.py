@@ -37,7 +37,7 @@ class FDBurgers:
         if use_fd_jacobian:
             raise NotImplementedError("the finite-difference Jacobian is a debugging aid of the reference; "
                                       "the HIP path implements the analytical Jacobian")
-        batched = np.ndim(mu1) > 0 or np.ndim(mu2) > 0
+        batched = np.ndim(mu1) > 0 or np.ndim(mu2) > 0 or np.ndim(U0) > 1
         res = _fom.fd_run(self.a, self.b, self.N, np.asarray(U0, dtype=np.float64), mu1, mu2, dt, int(n_steps),
                           max_iter=max_iter, tol=tol)
         U = _lib.to_host(res.snapshots())

@@ -58,8 +58,8 @@ class FEMBurgers:
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
-    def _batched(mu1, mu2):
-        return np.ndim(mu1) > 0 or np.ndim(mu2) > 0
+    def _batched(mu1, mu2, u0=None):
+        return np.ndim(mu1) > 0 or np.ndim(mu2) > 0 or np.ndim(u0) > 1
 
     def _finish(self, res, batched):
         snaps = res.snapshots()                       # (B, N, nT+1) on device
@@ -79,7 +79,7 @@ class FEMBurgers:
     # ---------------------------------------------------------------------- FOM
     def fom_burgers(self, At, nTimeSteps, u0, mu1, E, mu2):
         """Implicit-Euler / Picard FOM (reference :646-707).  Returns ``(N, nTimeSteps+1)``."""
-        batched = self._batched(mu1, mu2)
+        batched = self._batched(mu1, mu2, u0)
         res = _fom.fom_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps), E=E,
                            tol=1e-6, max_it=20, supg=True)
         return self._finish(res, batched)
@@ -88,7 +88,7 @@ class FEMBurgers:
     def pod_prom_burgers(self, At, nTimeSteps, u0, mu1, E, mu2, Phi, projection="Galerkin"):
         """POD projection ROM (reference :709-785).  ``projection`` is "Galerkin" or "LSPG",
         case-sensitive as in the reference; anything else raises ValueError."""
-        batched = self._batched(mu1, mu2)
+        batched = self._batched(mu1, mu2, u0)
         res = _rom.pod_prom_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps),
                                 np.asarray(Phi, dtype=np.float64), projection=projection, E=E)
         return self._finish(res, batched)
@@ -97,7 +97,7 @@ class FEMBurgers:
     def pod_quadratic_manifold(self, At, nTimeSteps, u0, uxa, E, mu2, Phi, H, projection="LSPG",
                                newton_tol=1e-6, newton_itmax=25):
         """Quadratic-manifold PROM (reference :1081-1175); ``uxa`` is the left Dirichlet value."""
-        batched = self._batched(uxa, mu2)
+        batched = self._batched(uxa, mu2, u0)
         res = _rom.quadratic_run(self.X, np.asarray(u0, dtype=np.float64), uxa, mu2, At, int(nTimeSteps),
                                  np.asarray(Phi, dtype=np.float64), np.asarray(H, dtype=np.float64),
                                  projection=projection, E=E, newton_tol=newton_tol, newton_itmax=newton_itmax)
@@ -110,7 +110,7 @@ class FEMBurgers:
         """POD-ANN PROM (reference :1177-1251).  ``model`` is any torch.nn.Module mapping
         (., n) -> (., nbar); it is borrowed and evaluated in float32 like the reference."""
         import copy
-        batched = self._batched(mu1, mu2)
+        batched = self._batched(mu1, mu2, u0)
         res = _rom.pod_ann_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps),
                                np.asarray(U_p, dtype=np.float64), np.asarray(U_s, dtype=np.float64),
                                copy.deepcopy(model), projection=projection, E=E)
@@ -121,7 +121,7 @@ class FEMBurgers:
                      x_min, x_max, y_min, y_max, projection="LSPG", kernel="gaussian",
                      tol_newton=1e-6, max_newton=30):
         """POD-RBF PROM with the scaled Gaussian / IMQ closure (reference :1278-1398)."""
-        batched = self._batched(mu1, mu2)
+        batched = self._batched(mu1, mu2, u0)
         res = _rom.pod_rbf_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps), U_p, U_s,
                                X_train, W, epsilon, x_min, x_max, y_min, y_max, projection=projection,
                                kernel=kernel, E=E, tol_newton=tol_newton, max_newton=max_newton)
@@ -133,7 +133,7 @@ class FEMBurgers:
         """Local (clustered) POD PROM (reference :979-1079).  ``kmeans`` is the fitted
         scikit-learn KMeans of the reference (only ``cluster_centers_`` is used: ``predict`` is the
         nearest centre), ``local_bases`` a dict cluster id -> (N, r_c) basis."""
-        batched = self._batched(mu1, mu2)
+        batched = self._batched(mu1, mu2, u0)
         res = _rom.local_prom_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps),
                                   np.asarray(kmeans.cluster_centers_, dtype=np.float64), local_bases, U_global,
                                   int(num_global_modes), projection=projection, E=E)

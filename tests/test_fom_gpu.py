@@ -412,3 +412,24 @@ def test_workgroup_wide_fd_stepper(hip, N):
     for b in range(B):
         Uo, ito = br.fd_newton(0.0, 100.0, N, dt, 5, np.ones(N), mu1[b], mu2[b], return_iters=True)
         assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < TOL and np.array_equal(res.iters[b].cpu().numpy(), ito)
+
+
+def test_facade_batch_broadcasting(hip):
+    """u0, mu1, mu2 broadcast to one batch size; anything else is a ValueError, not a silent broadcast."""
+    from fem_burgers import FEMBurgers
+    N = 64
+    X, T = mesh(N)
+    fem = FEMBurgers(X, T)
+    u0 = np.ones(N)
+    assert fem.fom_burgers(0.05, 3, list(u0), 5, 0.0, np.array(0.02)).shape == (N, 4)
+    assert fem.fom_burgers(0.05, 3, u0.astype(np.float32), np.array([4.5, 4.6, 4.7]), 0.0, 0.02).shape == (3, N, 4)
+    U = fem.fom_burgers(0.05, 3, np.stack([u0, 1.1 * u0]), 4.5, 0.0, 0.02)        # batch from u0 alone
+    assert U.shape == (2, N, 4) and np.allclose(U[1, :, 0], 1.1) and not np.allclose(U[0], U[1])
+    with pytest.raises(ValueError):
+        fem.fom_burgers(0.05, 3, u0, np.array([4.5, 4.6, 4.7]), 0.0, np.array([0.02, 0.03]))
+    with pytest.raises(ValueError):
+        fem.fom_burgers(0.05, 3, np.ones(N + 1), 4.5, 0.0, 0.02)
+    Phi = np.linalg.qr(np.random.default_rng(0).standard_normal((N, 5)))[0]
+    with pytest.raises(ValueError):
+        fem.pod_prom_burgers(0.05, 3, u0, np.array([4.5, 4.6]), 0.0, np.array([0.02, 0.03, 0.04]), Phi)
+    assert fem.pod_prom_burgers(0.05, 3, u0, 4.5, 0.0, 0.02, np.asfortranarray(Phi)).shape == (N, 4)
