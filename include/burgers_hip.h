@@ -147,7 +147,9 @@ int bg_mass_rhs(int N, int B, const double *x, const double *un, const double *f
  *   active   [B] int32 or NULL: samples with 0 are skipped and their outputs left untouched
  *   Ar       [B][r][r]: W^T A W (BG_PROJ_GALERKIN) or (A W)^T (A W) (BG_PROJ_LSPG)
  *   br       [B][r]:    W^T R   or (A W)^T R,  R = A u_k - b
- *   wtu      [B][r] or NULL: W^T u_k (the `Phi.T @ U0` of :770) */
+ *   wtu      [B][r] or NULL: W^T u_k (the `Phi.T @ U0` of :770)
+ *   Two kernels: v_mfma_f64_4x4x4_4b (r <= 40) and v_mfma_f64_16x16x4 (r <= 47).  The environment variable
+ *   BG_ROM_FORCE_16X16 (any value) selects the second one for every r, for A/B timing and tests. */
 int bg_rom_reduce(int N, int B, int r, int projection, const double *x, const double *W,
                   long long w_stride, const double *U, const double *G, const double *hfs,
                   const double *mu1, double dt, double E, int supg, const int32_t *active,

@@ -554,3 +554,35 @@ def test_rbf_closure_kernel(hip):
             assert np.abs(val[b] - br.rbf_value(qp[b], *args)).max() < 1e-11 * max(1.0, np.abs(val[b]).max())
             jo = br.rbf_jacobian(qp[b], *args)
             assert np.abs(jac[b] - jo).max() < 1e-10 * np.abs(jo).max()
+
+
+def test_both_mfma_kernels_agree(hip):
+    """The 16x16x4 kernel (default only for 40 < r <= 47) forced for r = 40 / 24 gives the 4x4x4 kernel's results."""
+    import os
+    from burgers_hip import rom
+    rng = np.random.default_rng(99)
+    N, B = 512, 6
+    X, _ = mesh(N)
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    U = 1.0 + 4.0 * rng.random((B, N)); Un = 1.0 + 4.0 * rng.random((B, N))
+    c = rom._setup(X, Un, mu1, mu2, 0.05, 0.0, None)
+    G = torch.empty((B, N), dtype=torch.float64, device="cuda")
+    rom._mass_rhs(c, _dev(Un), G)
+    for r in (40, 24):
+        W = _dev(np.linalg.qr(rng.standard_normal((N, r)))[0])
+        for proj in (0, 1):
+            out = []
+            for force in (False, True):
+                if force:
+                    os.environ["BG_ROM_FORCE_16X16"] = "1"
+                try:
+                    Ar = torch.zeros((B, r, r), dtype=torch.float64, device="cuda")
+                    brr = torch.zeros((B, r), dtype=torch.float64, device="cuda")
+                    wtu = torch.zeros((B, r), dtype=torch.float64, device="cuda")
+                    rom.rom_reduce(c, W, _dev(U), G, proj, True, None, Ar, brr, wtu)
+                    torch.cuda.synchronize()
+                finally:
+                    os.environ.pop("BG_ROM_FORCE_16X16", None)
+                out.append((Ar.cpu().numpy(), brr.cpu().numpy(), wtu.cpu().numpy()))
+            for a, b in zip(*out):
+                assert rel_l2(a, b) < 1e-13
