@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""One-off differential fuzz of bg_rom_reduce* (all basis layouts) and bg_lu_solve against the oracle / numpy.
+usage: fuzz_rom.py [n_cases] [seed]"""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "1d-burgers-equation-roms_amd"))
+import numpy as np, torch
+from burgers_hip import rom
+from oracle import burgers_ref as br
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
+dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+bad, worst = 0, 0.0
+t0 = time.time()
+for case in range(n_cases):
+    N = int(rng.integers(2, 513)); r = int(rng.integers(1, 48)); B = int(rng.integers(1, 7))
+    X = np.linspace(0.0, 100.0, N)
+    if rng.random() < 0.3 and N > 3:
+        w = rng.uniform(0.6, 1.4, N - 1); X = np.concatenate([[0.0], np.cumsum(w)]) * (100.0 / w.sum())
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    dt, E = float(rng.uniform(0.01, 0.06)), float(rng.choice([0.0, 0.004]))
+    U = 1.0 + 4.0 * rng.random((B, N)); Un = 1.0 + 4.0 * rng.random((B, N))
+    supg = bool(rng.random() < 0.7)
+    layout = rng.choice(["shared", "persample", "colmajor", "indexed"])
+    C = int(rng.integers(1, 4))
+    stack = rng.standard_normal((C, N, r)); idx = rng.integers(0, C, B)
+    Wper = rng.standard_normal((B, N, r)); Wsh = rng.standard_normal((N, r))
+    Wb = {"shared": lambda b: Wsh, "persample": lambda b: Wper[b], "colmajor": lambda b: Wper[b], "indexed": lambda b: stack[idx[b]]}[layout]
+    act = (rng.random(B) < 0.8).astype(np.int32); act[0] = 1
+    c = rom._setup(X, Un, mu1, mu2, dt, E, None)
+    G = torch.empty((B, N), dtype=torch.float64, device="cuda"); rom._mass_rhs(c, dev(Un), G)
+    M3, K3 = br.mass_tridiag(X), br.diffusion_tridiag(X)
+    for pname, proj in (("galerkin", 0), ("lspg", 1)):
+        Ar = torch.full((B, r, r), 7.0, dtype=torch.float64, device="cuda"); brr = torch.full((B, r), 7.0, dtype=torch.float64, device="cuda")
+        wtu = torch.full((B, r), 7.0, dtype=torch.float64, device="cuda")
+        a = torch.as_tensor(act, device="cuda")
+        if layout == "shared": rom.rom_reduce(c, dev(Wsh), dev(U), G, proj, supg, a, Ar, brr, wtu)
+        elif layout == "persample": rom.rom_reduce(c, dev(Wper), dev(U), G, proj, supg, a, Ar, brr, wtu)
+        elif layout == "colmajor": rom.rom_reduce(c, dev(Wper.transpose(0, 2, 1)), dev(U), G, proj, supg, a, Ar, brr, wtu, colmajor=True)
+        else: rom.rom_reduce(c, dev(stack), dev(U), G, proj, supg, a, Ar, brr, wtu, w_index=torch.as_tensor(idx.astype(np.int32), device="cuda"))
+        torch.cuda.synchronize()
+        Arh, brh, wth = Ar.cpu().numpy(), brr.cpu().numpy(), wtu.cpu().numpy()
+        for b in range(B):
+            if not act[b]:
+                ok = (Arh[b] == 7.0).all() and (brh[b] == 7.0).all()
+                e = 0.0
+            else:
+                lo, di, up = br.system_tridiag(M3, K3, br.convection_tridiag(X, U[b]), dt, E)
+                bb = br.tridiag_matvec(*M3, Un[b]) + dt * br.forcing_vector(X, mu2[b])
+                if supg: bb = bb - dt * br.supg_term(X, U[b], mu2[b])
+                bb[0] = mu1[b]
+                R = br.tridiag_matvec(lo, di, up, U[b]) - bb
+                A_ref, b_ref = br._reduce(lo, di, up, R, Wb(b), pname)
+                e = max(rel(Arh[b], A_ref), rel(brh[b], b_ref) * 0.1, rel(wth[b], Wb(b).T @ U[b]))
+                ok = e < 1e-12
+            worst = max(worst, e)
+            if not ok:
+                bad += 1; print(f"REDUCE MISMATCH case {case}: N={N} r={r} B={B} {layout} {pname} supg={supg} b={b} act={act[b]} e={e:.2e}", flush=True)
+    # LU: graded random systems
+    n = int(rng.integers(1, 65)); Bl = int(rng.integers(1, 9))
+    A = rng.standard_normal((Bl, n, n)) * np.logspace(0, -rng.uniform(0, 6), n)[None, None, :] + 0.1 * np.eye(n)
+    rhs = rng.standard_normal((Bl, n))
+    x, info = rom.lu_solve(dev(A), dev(rhs), 1.0); torch.cuda.synchronize()
+    xr = np.linalg.solve(A, rhs[..., None])[..., 0]
+    for b in range(Bl):
+        cond = np.linalg.cond(A[b]); e = rel(x[b].cpu().numpy(), xr[b])
+        if not (e < 1e-13 * max(cond, 10.0) and int(info[b]) == 0):
+            bad += 1; print(f"LU MISMATCH case {case}: n={n} cond={cond:.1e} e={e:.2e} info={int(info[b])}", flush=True)
+    if case % 25 == 24:
+        print(f"{case + 1} cases, worst reduce err {worst:.2e}, mismatches {bad}, {time.time() - t0:.0f} s", flush=True)
+print(f"done: {n_cases} cases, worst reduce err {worst:.2e}, mismatches {bad}")
+sys.exit(1 if bad else 0)
