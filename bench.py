@@ -50,27 +50,11 @@ def workload(args, rank):
     return mu1[sl], mu2[sl]
 
 
-def cpu_baseline(args, mu1, mu2):
-    """C oracle (a port of the reference algorithm) on the host cores, bounded sample."""
-    from oracle import burgers_ref_c as bc
-    X = np.linspace(0.0, 100.0, args.n)
-    threads = bc.max_threads()
-    nb = min(len(mu1), max(threads * 8, 16))
-    steps = min(args.time_steps, args.cpu_steps)
-    bc.fom_run(X, np.ones(args.n), mu1[:2], mu2[:2], args.dt, 2)          # warm the thread pool
-    t0 = time.perf_counter()
-    _, iters = bc.fom_run(X, np.ones(args.n), mu1[:nb], mu2[:nb], args.dt, steps)
-    t = time.perf_counter() - t0
-    return {
-        "value": float(iters.sum() / t), "unit": "sample-Newton-steps/s", "cores": int(threads),
-        "kind": "port",
-        "sample": f"{nb} samples x first {steps} time steps of the same workload, C oracle + OpenMP, {t:.1f} s",
-        "reference_as_written": "about 8 Newton-steps/s on 1 core at N=1024 (Python element loops; BASELINE.md section 2, survey container)",
-    }
-
-
-def parity_probe(args, hist, iters, mu1, mu2, nsub=4):
-    """rel-L2 of a few full trajectories against the CPU oracle (outside the timed region)."""
+def cpu_leg(args, mu1, mu2, hist, iters, timed, nsub=4):
+    """The CPU-reference leg -- the ONLY place bench.py touches oracle/ (test infrastructure: the C restatement of
+    the reference algorithm), outside the timed region.  Always: rel-L2 and iteration counts of a few full
+    trajectories of this rank's result against it (BASELINE.json's "rel-L2 vs CPU ref").  With ``timed`` (N=1
+    only): the same code on the host cores over a bounded sample of the workload = ``cpu_baseline``."""
     from oracle import burgers_ref_c as bc
     X = np.linspace(0.0, 100.0, args.n)
     idx = np.linspace(0, len(mu1) - 1, nsub).astype(int)
@@ -78,7 +62,22 @@ def parity_probe(args, hist, iters, mu1, mu2, nsub=4):
     hg = hist[torch.as_tensor(idx, device=hist.device)].cpu().numpy()
     ig = iters[torch.as_tensor(idx, device=hist.device)].cpu().numpy()
     rel = float(np.linalg.norm(hg - ho) / np.linalg.norm(ho))
-    return rel, bool(np.array_equal(ig, ito))
+    iters_ok = bool(np.array_equal(ig, ito))
+    if not timed:
+        return rel, iters_ok, None
+    threads = bc.max_threads()
+    nb = min(len(mu1), max(threads * 8, 16))
+    steps = min(args.time_steps, args.cpu_steps)
+    bc.fom_run(X, np.ones(args.n), mu1[:2], mu2[:2], args.dt, 2)          # warm the thread pool
+    t0 = time.perf_counter()
+    _, it_cpu = bc.fom_run(X, np.ones(args.n), mu1[:nb], mu2[:nb], args.dt, steps)
+    t = time.perf_counter() - t0
+    return rel, iters_ok, {
+        "value": float(it_cpu.sum() / t), "unit": "sample-Newton-steps/s", "cores": int(threads),
+        "kind": "port",
+        "sample": f"{nb} samples x first {steps} time steps of the same workload, C oracle + OpenMP, {t:.1f} s",
+        "reference_as_written": "about 8 Newton-steps/s on 1 core at N=1024 (Python element loops; BASELINE.md section 2, survey container)",
+    }
 
 
 def measured_traffic():
@@ -174,7 +173,8 @@ def main():
         alg_bytes_per_step = 3 * 8 * args.n              # read u_k, read u^n, write u_{k+1}
         avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
         achieved = steps_per_pass * alg_bytes_per_step / avg_kernel_s / 1e9
-        rel, iters_ok = parity_probe(args, out.hist, out.iters, mu1, mu2)
+        rel, iters_ok, cpu = cpu_leg(args, mu1, mu2, out.hist, out.iters,
+                                     timed=(args.gpus == 1 and not args.no_cpu_baseline))
         line = {
             "metric": "batched Newton-steps/sec over mu-sweep (sample-Newton-steps/s, FOM N=%d)" % args.n,
             "value": value, "unit": "sample-Newton-steps/s", "n_gpus": args.gpus, "steps": args.steps,
@@ -198,8 +198,8 @@ def main():
                                        "frac": steps_per_pass * FLOP_PER_ROW_STEP * args.n / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TF,
                                        "flop_per_row_step": FLOP_PER_ROW_STEP}},
         }
-        if args.gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, mu1, mu2)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -2,7 +2,7 @@
 """One-off differential fuzz of bg_fom_run / bg_fd_run against the oracles over many random sizes and settings.
 usage: fuzz_fom.py [n_cases] [seed]"""
 import os, sys, time
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "1d-burgers-equation-roms_amd"))
 import numpy as np, torch
 from burgers_hip import fom
