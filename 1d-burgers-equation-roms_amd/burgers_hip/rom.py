@@ -76,7 +76,7 @@ def _mass_rhs(c, Un, out):
     return out
 
 
-def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None, colmajor=False, w_index=None):
+def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None, colmajor=False, w_index=None, extra_opts=0):
     """Ar, br (and optionally W^T u) of every active sample.  W: (N, r) shared or (B, N, r);
     with ``colmajor`` the transposed blocks (r, N) / (B, r, N); with ``w_index`` (B,) int32 a stack
     (C, N, r) of bases of which sample b uses block w_index[b]."""
@@ -85,7 +85,7 @@ def rom_reduce(c, W, U, G, proj, supg, active, Ar, br, wtu=None, colmajor=False,
         Wl = W if w_index is None else W[w_index.long()]
         return _rom_reduce_library(c, Wl.transpose(-1, -2) if colmajor else Wl, U, proj, supg, active, Ar, br, wtu)
     stride = 0 if W.dim() == 2 else c.N * r
-    opts = (1 if supg else 0) | c.mesh_opt | (_lib.BG_OPT_W_COLMAJOR if colmajor else 0)
+    opts = (1 if supg else 0) | c.mesh_opt | (_lib.BG_OPT_W_COLMAJOR if colmajor else 0) | extra_opts
     if w_index is not None:
         with torch.cuda.device(c.device):
             rc = c.L.bg_rom_reduce_indexed(c.N, c.B, r, proj, _lib.ptr(c.X), _lib.ptr(W), stride, _lib.ptr(w_index),
@@ -142,13 +142,13 @@ def lu_solve(A, b, sign=1.0, active=None, x=None, info=None):
     return x, info
 
 
-def rom_reduce_lifted(c, Phi, q, U, G, proj, supg, active, Ar, br, wtu):
+def rom_reduce_lifted(c, Phi, q, U, G, proj, supg, active, Ar, br, wtu, extra_opts=0):
     """bg_rom_reduce with u = Phi q formed in-kernel (and stored to U)."""
     r = Phi.shape[1]
     with torch.cuda.device(c.device):
         rc = c.L.bg_rom_reduce_lifted(c.N, c.B, r, proj, _lib.ptr(c.X), _lib.ptr(Phi), _lib.ptr(q), _lib.ptr(U),
                                       _lib.ptr(G), _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E,
-                                      (1 if supg else 0) | c.mesh_opt, _lib.ptr(active) if active is not None else None, _lib.ptr(Ar), _lib.ptr(br),
+                                      (1 if supg else 0) | c.mesh_opt | extra_opts, _lib.ptr(active) if active is not None else None, _lib.ptr(Ar), _lib.ptr(br),
                                       _lib.ptr(wtu) if wtu is not None else None, c.stream())
     if rc == _lib.BG_ERR_UNSUPPORTED_R:
         raise NotImplementedError(f"ROM kernels cover r <= {c.L.bg_rom_max_r()} (got {r})")

@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include "../../include/burgers_hip.h"
+#include "abi_common.hpp"
 #include "fom_device.hpp"
 #include "fom_wide.hpp"
 
@@ -219,7 +220,7 @@ extern "C" int bg_fd_run(int N, int B, int nsteps, const double* x, const double
         else if (rw <= 16) hipLaunchKernelGGL((fd_wide_kernel<16>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
         else if (rw <= 24) hipLaunchKernelGGL((fd_wide_kernel<24>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
         else hipLaunchKernelGGL((fd_wide_kernel<32>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
-        return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_LAUNCH;
+        return bg::check_launch();
     }
     const int r = (N + 63) / 64;
 #define BG_FD(RV) hipLaunchKernelGGL((fd_fused_kernel<RV>), grid, block, 0, st, a)
@@ -232,5 +233,5 @@ extern "C" int bg_fd_run(int N, int B, int nsteps, const double* x, const double
     else if (r <= 24) BG_FD(24);
     else BG_FD(32);
 #undef BG_FD
-    return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_LAUNCH;
+    return bg::check_launch();
 }

@@ -9,14 +9,17 @@
 #include <type_traits>
 
 #include "../../include/burgers_hip.h"
+#include "abi_common.hpp"
 #include "fom_device.hpp"
 #include "fom_wide.hpp"
+
+namespace bg {
+thread_local int tls_last_hip_error = 0;
+}
 
 namespace {
 
 using namespace bg;
-
-thread_local int g_last_hip_error = 0;
 
 struct FomArgs {
     const double* x;
@@ -306,16 +309,6 @@ int rows_per_lane(int N)
     return 0;
 }
 
-int check_launch()
-{
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        g_last_hip_error = (int)e;
-        return BG_ERR_LAUNCH;
-    }
-    return BG_OK;
-}
-
 // workgroup-per-sample kernels: 8, 12, 16, 24 or 32 rows per THREAD of a 256-thread workgroup
 // Measured (tools/time_wide.py, B = 1024): at 32 rows per lane the wave-per-sample kernel spills (N = 2048:
 // 1.1e8 steps/s, N = 1800: 3.4e7) and the workgroup kernel at 8 rows per thread wins (1.29e8 / 1.24e8); at 24
@@ -359,7 +352,7 @@ extern "C" {
 
 int bg_abi_version(void) { return BG_ABI_VERSION; }
 
-int bg_last_hip_error(void) { return g_last_hip_error; }
+int bg_last_hip_error(void) { return bg::tls_last_hip_error; }
 
 int bg_fom_max_n(void) { return kWideMaxN; }
 

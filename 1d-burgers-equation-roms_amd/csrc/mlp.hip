@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/burgers_hip.h"
+#include "abi_common.hpp"
 
 namespace {
 
@@ -58,5 +59,5 @@ extern "C" int bg_mlp_act_jvp(int B, int n1, int h, float* z, const float* bias,
         case BG_ACT_RELU: hipLaunchKernelGGL(mlp_act_jvp_kernel<BG_ACT_RELU>, grid, block, 0, st, z, bias, total, n1, h, alpha); break;
         default: hipLaunchKernelGGL(mlp_act_jvp_kernel<BG_ACT_TANH>, grid, block, 0, st, z, bias, total, n1, h, alpha); break;
     }
-    return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_LAUNCH;
+    return bg::check_launch();
 }

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "../../include/burgers_hip.h"
+#include "abi_common.hpp"
 
 namespace {
 
@@ -70,5 +71,5 @@ extern "C" int bg_rbf_eval(int B, int n, int Ns, int kind, double eps, const dou
         hipLaunchKernelGGL(rbf_eval_kernel<BG_RBF_GAUSSIAN>, grid, block, lds, st, qp, x_min, dx, XtT, phi, GT, B, n, Ns, eps * eps);
     else
         hipLaunchKernelGGL(rbf_eval_kernel<BG_RBF_IMQ>, grid, block, lds, st, qp, x_min, dx, XtT, phi, GT, B, n, Ns, eps * eps);
-    return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_LAUNCH;
+    return bg::check_launch();
 }

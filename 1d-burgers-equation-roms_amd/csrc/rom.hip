@@ -11,10 +11,10 @@
 // contractions over the whole batch and live on the host side (burgers_hip/rom.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <type_traits>
 
 #include "../../include/burgers_hip.h"
+#include "abi_common.hpp"
 #include "fom_device.hpp"
 
 namespace {
@@ -23,12 +23,6 @@ using namespace bg;
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
-
-int check_launch_rom()
-{
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? BG_OK : BG_ERR_LAUNCH;
-}
 
 // ------------------------------------------------------------------------------------
 // Per-sample constants: fdt[b][i] = dt*F_i(mu2_b), hfs[b][e] = h*(f(gp1)+f(gp2)) of element e
@@ -794,7 +788,7 @@ int bg_forcing_setup(int N, int B, const double* x, const double* mu2, double dt
     if (!x || !mu2 || !fdt || !hfs) return BG_ERR_BAD_ARG;
     hipLaunchKernelGGL(forcing_setup_kernel, dim3((N + 255) / 256, B < 65535 ? B : 65535), dim3(256), 0, (hipStream_t)stream, x, mu2, N,
                        B, dt, (options & BG_OPT_NONUNIFORM) ? 1 : 0, fdt, hfs);
-    return check_launch_rom();
+    return check_launch();
 }
 
 int bg_mass_rhs(int N, int B, const double* x, const double* un, const double* fdt, int options, double* g,
@@ -805,7 +799,7 @@ int bg_mass_rhs(int N, int B, const double* x, const double* un, const double* f
     if (!x || !un || !fdt || !g) return BG_ERR_BAD_ARG;
     hipLaunchKernelGGL(mass_rhs_kernel, dim3((N + 255) / 256, B < 65535 ? B : 65535), dim3(256), 0, (hipStream_t)stream, x, un, fdt, N, B,
                        (options & BG_OPT_NONUNIFORM) ? 1 : 0, g);
-    return check_launch_rom();
+    return check_launch();
 }
 
 int bg_rom_max_n(void) { return 512; }
@@ -831,15 +825,13 @@ static int rom_reduce_impl(int N, int B, int r, int projection, const double* x,
     a.q_in = q_in; a.Uout = Uout; a.lift_only = lift_only; a.w_frag = w_frag;
     a.w_colmajor = (supg & BG_OPT_W_COLMAJOR) ? 1 : 0;
     a.w_index = w_index;
-    if (w_frag && (r > 40 || getenv("BG_ROM_FORCE_16X16"))) return BG_ERR_UNSUPPORTED_R;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        cus = 256;
+    const bool force16 = (supg & BG_OPT_MFMA_16X16) != 0;
+    if (w_frag && (r > 40 || force16)) return BG_ERR_UNSUPPORTED_R;
+    const int cus = device_cu_count();
     const int grid = B < cus ? B : cus;
     hipStream_t st = (hipStream_t)stream;
     // fast path: v_mfma_f64_4x4x4_4b kernel, r <= 40 (accumulators and fragments must fit the register file)
-    if (r <= 40 && !getenv("BG_ROM_FORCE_16X16")) {
+    if (r <= 40 && !force16) {
         const int nb = r <= 8 ? 2 : (r <= 16 ? 4 : (r <= 24 ? 6 : (r <= 32 ? 8 : 10)));
         const bool want_wtu = wtu != nullptr;
         const bool gal = projection == BG_PROJ_GALERKIN;
@@ -867,7 +859,7 @@ static int rom_reduce_impl(int N, int B, int r, int projection, const double* x,
             default: return BG_ERR_UNSUPPORTED_R;
         }
 #undef BG_LAUNCH_R4
-        return check_launch_rom();
+        return check_launch();
     }
     const int S = N <= 128 ? 8 : (N <= 256 ? 16 : 32);
     const int NT = (r + 1 + 15) / 16;     // room for the extra column that carries R
@@ -891,7 +883,7 @@ static int rom_reduce_impl(int N, int B, int r, int projection, const double* x,
         default: return BG_ERR_UNSUPPORTED_R;
     }
 #undef BG_LAUNCH_REDUCE
-    return check_launch_rom();
+    return check_launch();
 }
 
 int bg_rom_reduce(int N, int B, int r, int projection, const double* x, const double* W, long long w_stride,
@@ -960,7 +952,7 @@ int bg_quad_tangent(int N, int B, int n, const double* Phi, const double* H3, co
         default: return BG_ERR_UNSUPPORTED_R;
     }
 #undef BG_QT
-    return check_launch_rom();
+    return check_launch();
 }
 
 int bg_rom_reduce_frag(int N, int B, int r, int projection, const double* x, const double* Wfrag, const double* U,
@@ -994,7 +986,7 @@ int bg_lu_solve_update(int n, int B, const double* A, const double* b, int mode,
     return dispatch_lu(n, [&](auto nc) {
         constexpr int NMAX = decltype(nc)::value;
         hipLaunchKernelGGL((lu_solve_kernel<NMAX>), dim3((B + 3) / 4), dim3(256), 0, st, a);
-        return check_launch_rom();
+        return check_launch();
     });
 }
 
@@ -1009,7 +1001,7 @@ int bg_lu_solve(int n, int B, const double* A, const double* b, double sign, con
     return dispatch_lu(n, [&](auto nc) {
         constexpr int NMAX = decltype(nc)::value;
         hipLaunchKernelGGL((lu_solve_kernel<NMAX>), dim3((B + 3) / 4), dim3(256), 0, st, a);
-        return check_launch_rom();
+        return check_launch();
     });
 }
 

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "../../include/burgers_hip.h"
+#include "abi_common.hpp"
 #include "wave_ops.hpp"
 
 namespace {
@@ -72,5 +73,5 @@ extern "C" int bg_jacobi_sweep(int m, int ld, double* G, double* J, const int32_
     for (int s = 0; s < n_steps; ++s)
         hipLaunchKernelGGL(jacobi_pair_kernel, dim3(n_pairs), dim3(256), 0, st, G, J, m, ld,
                            pairs + (size_t)s * n_pairs * 2, tol, rotations);
-    return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_LAUNCH;
+    return bg::check_launch();
 }

@@ -45,7 +45,8 @@ enum { BG_PROJ_GALERKIN = 0, BG_PROJ_LSPG = 1 };
 /* option bits of the `supg` / `options` argument of the assembly-carrying entry points */
 enum { BG_OPT_SUPG = 1,        /* include the SUPG vector (fom_burgers, pod_prom_burgers, pod_ann_prom) */
        BG_OPT_NONUNIFORM = 2,  /* x is not a linspace: use the per-element-length kernels          */
-       BG_OPT_W_COLMAJOR = 4   /* bg_rom_reduce*: W is [r][N] (per sample), not [N][r]             */ };
+       BG_OPT_W_COLMAJOR = 4,  /* bg_rom_reduce*: W is [r][N] (per sample), not [N][r]             */
+       BG_OPT_MFMA_16X16 = 8   /* bg_rom_reduce*: use the v_mfma_f64_16x16x4 kernel for every r (A/B timing, tests) */ };
 
 /* per-sample status bits written to `flags` */
 enum { BG_FLAG_HIT_CAP = 1, BG_FLAG_NONFINITE = 2 };
@@ -148,8 +149,8 @@ int bg_mass_rhs(int N, int B, const double *x, const double *un, const double *f
  *   Ar       [B][r][r]: W^T A W (BG_PROJ_GALERKIN) or (A W)^T (A W) (BG_PROJ_LSPG)
  *   br       [B][r]:    W^T R   or (A W)^T R,  R = A u_k - b
  *   wtu      [B][r] or NULL: W^T u_k (the `Phi.T @ U0` of :770)
- *   Two kernels: v_mfma_f64_4x4x4_4b (r <= 40) and v_mfma_f64_16x16x4 (r <= 47).  The environment variable
- *   BG_ROM_FORCE_16X16 (any value) selects the second one for every r, for A/B timing and tests. */
+ *   Two kernels: v_mfma_f64_4x4x4_4b (r <= 40) and v_mfma_f64_16x16x4 (r <= 47).  BG_OPT_MFMA_16X16 in `supg`
+ *   selects the second one for every r, for A/B timing and tests (no environment is read). */
 int bg_rom_reduce(int N, int B, int r, int projection, const double *x, const double *W,
                   long long w_stride, const double *U, const double *G, const double *hfs,
                   const double *mu1, double dt, double E, int supg, const int32_t *active,

@@ -557,8 +557,7 @@ def test_rbf_closure_kernel(hip):
 
 
 def test_both_mfma_kernels_agree(hip):
-    """The 16x16x4 kernel (default only for 40 < r <= 47) forced for r = 40 / 24 gives the 4x4x4 kernel's results."""
-    import os
+    """The 16x16x4 kernel (default only for 40 < r <= 47) forced for r = 40 / 24 (BG_OPT_MFMA_16X16) gives the 4x4x4 kernel's results."""
     from burgers_hip import rom
     rng = np.random.default_rng(99)
     N, B = 512, 6
@@ -573,16 +572,12 @@ def test_both_mfma_kernels_agree(hip):
         for proj in (0, 1):
             out = []
             for force in (False, True):
-                if force:
-                    os.environ["BG_ROM_FORCE_16X16"] = "1"
-                try:
-                    Ar = torch.zeros((B, r, r), dtype=torch.float64, device="cuda")
-                    brr = torch.zeros((B, r), dtype=torch.float64, device="cuda")
-                    wtu = torch.zeros((B, r), dtype=torch.float64, device="cuda")
-                    rom.rom_reduce(c, W, _dev(U), G, proj, True, None, Ar, brr, wtu)
-                    torch.cuda.synchronize()
-                finally:
-                    os.environ.pop("BG_ROM_FORCE_16X16", None)
+                Ar = torch.zeros((B, r, r), dtype=torch.float64, device="cuda")
+                brr = torch.zeros((B, r), dtype=torch.float64, device="cuda")
+                wtu = torch.zeros((B, r), dtype=torch.float64, device="cuda")
+                rom.rom_reduce(c, W, _dev(U), G, proj, True, None, Ar, brr, wtu,
+                               extra_opts=hip.BG_OPT_MFMA_16X16 if force else 0)
+                torch.cuda.synchronize()
                 out.append((Ar.cpu().numpy(), brr.cpu().numpy(), wtu.cpu().numpy()))
             for a, b in zip(*out):
                 assert rel_l2(a, b) < 1e-13

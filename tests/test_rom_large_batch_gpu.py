@@ -1,0 +1,423 @@
+"""GPU parity of the ROM kernels on the path production batches take: MORE samples than workgroups.
+
+bg_rom_reduce* launches min(B, #CUs) workgroups; beyond that every workgroup walks over several
+samples with the basis fragments kept in registers, the per-sample rows double-buffered in LDS and
+the NEXT sample prefetched by LDS DMA under the current sample's MFMAs (csrc/rom.hip,
+rom_reduce4_kernel).  Every test here uses B >= 4 x 256 so that this loop really iterates, and checks
+  (i)  a strided subset of the samples against the oracle (oracle/burgers_ref.py), and
+  (ii) ALL samples bit-for-bit against the same call split into chunks of <= 200 samples, i.e. the
+       one-sample-per-workgroup path that tests/test_rom_gpu.py pins against the oracle.
+Shapes: BASELINE.json configs[2] (POD r = 40, B = 4096), configs[3] (quadratic manifold r = 40,
+k = 820, 1024 samples per GPU), configs[4] intrusive POD-ANN (2048 samples per GPU).
+reference: FEM/fem_burgers.py:754-776 (pod_prom_burgers), :1126-1173 (pod_quadratic_manifold),
+:1194-1249 (pod_ann_prom), :979-1079 (local_prom_burgers).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, mesh, rel_l2
+from oracle import burgers_ref as br
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+CHUNK = 200                     # < 256 CUs: one sample per workgroup
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+def _oracle_reduce(X, M3, K3, U, Un, mu1, mu2, dt, E, W, pname, supg):
+    lo, di, up = br.system_tridiag(M3, K3, br.convection_tridiag(X, U), dt, E)
+    bb = br.tridiag_matvec(*M3, Un) + dt * br.forcing_vector(X, mu2)
+    if supg:
+        bb = bb - dt * br.supg_term(X, U, mu2)
+    bb[0] = mu1
+    R = br.tridiag_matvec(lo, di, up, U) - bb
+    return br._reduce(lo, di, up, R, W, pname)
+
+
+class _Case:
+    """Random state for one reduce problem of B samples on an N-node mesh."""
+
+    def __init__(self, N, B, seed, dt=0.05, E=0.004):
+        from burgers_hip import rom
+        rng = np.random.default_rng(seed)
+        self.rng, self.N, self.B, self.dt, self.E = rng, N, B, dt, E
+        self.X, _ = mesh(N)
+        self.mu1 = rng.uniform(4.25, 5.5, B); self.mu2 = rng.uniform(0.015, 0.03, B)
+        self.U = 1.0 + 4.0 * rng.random((B, N)); self.Un = 1.0 + 4.0 * rng.random((B, N))
+        self.c = rom._setup(self.X, self.Un, self.mu1, self.mu2, dt, E, None)
+        self.G = torch.empty((B, N), dtype=torch.float64, device="cuda")
+        rom._mass_rhs(self.c, _dev(self.Un), self.G)
+        self.Ud = _dev(self.U)
+        self.M3, self.K3 = br.mass_tridiag(self.X), br.diffusion_tridiag(self.X)
+
+    def sub(self, lo, hi):
+        """The same problem restricted to samples [lo, hi): a fresh _Common over views of the big arrays."""
+        import copy
+        c = copy.copy(self.c)
+        c.B = hi - lo
+        c.mu1, c.mu2 = self.c.mu1[lo:hi].contiguous(), self.c.mu2[lo:hi].contiguous()
+        c.fdt, c.hfs = self.c.fdt[lo:hi].contiguous(), self.c.hfs[lo:hi].contiguous()
+        return c
+
+    def oracle(self, b, W, pname, supg, U=None):
+        return _oracle_reduce(self.X, self.M3, self.K3, self.U[b] if U is None else U, self.Un[b], self.mu1[b],
+                              self.mu2[b], self.dt, self.E, W, pname, supg)
+
+
+def _outs(B, r):
+    f64 = dict(dtype=torch.float64, device="cuda")
+    return (torch.full((B, r, r), -7.0, **f64), torch.full((B, r), -7.0, **f64), torch.full((B, r), -7.0, **f64))
+
+
+def _holes(B, rng):
+    """Active mask with holes: isolated zeros, a run longer than the grid stride pattern, a whole
+    workgroup column (every 256th sample from 5) switched off."""
+    a = np.ones(B, dtype=np.int32)
+    a[rng.choice(B, B // 7, replace=False)] = 0
+    a[300:340] = 0
+    a[5::256] = 0
+    a[0] = 1; a[B - 1] = 1
+    return a
+
+
+@pytest.mark.parametrize("N,r,B", [(512, 40, 1100), (512, 21, 1031), (511, 40, 1050), (300, 5, 1500), (255, 21, 1027),
+                                   (128, 33, 1040)])
+@pytest.mark.parametrize("force16", [False, True])
+def test_reduce_persistent_loop_shared_and_per_sample(hip, N, r, B, force16):
+    """bg_rom_reduce, shared and per-sample bases (row-major and column-major), both projections, both MFMA
+    kernels, even N (LDS-DMA prefetch) and odd N (plain staging), active masks with holes."""
+    from burgers_hip import rom
+    cs = _Case(N, B, 1000 * N + r)
+    rng = cs.rng
+    act = _holes(B, rng)
+    actd = _dev(act)
+    opts = hip.BG_OPT_MFMA_16X16 if force16 else 0
+    Wsh = rng.standard_normal((N, r))
+    Wps = rng.standard_normal((B, N, r))
+    probe = [b for b in np.linspace(0, B - 1, 9).astype(int) if act[b]] + [int(np.flatnonzero(act)[-1])]
+    for layout in ("shared", "per_sample", "colmajor"):
+        W = Wsh if layout == "shared" else Wps
+        Wd = _dev(W)
+        if layout == "colmajor":
+            Wd = Wd.transpose(1, 2).contiguous()
+        for pname, proj in (("galerkin", 0), ("lspg", 1)):
+            Ar, brr, wtu = _outs(B, r)
+            rom.rom_reduce(cs.c, Wd, cs.Ud, cs.G, proj, True, actd, Ar, brr, wtu, colmajor=(layout == "colmajor"),
+                           extra_opts=opts)
+            # (ii) the same samples, one per workgroup
+            Ar2, br2, wtu2 = _outs(B, r)
+            for lo in range(0, B, CHUNK):
+                hi = min(B, lo + CHUNK)
+                rom.rom_reduce(cs.sub(lo, hi), Wd if layout == "shared" else Wd[lo:hi], cs.Ud[lo:hi], cs.G[lo:hi], proj, True,
+                               actd[lo:hi], Ar2[lo:hi], br2[lo:hi], wtu2[lo:hi], colmajor=(layout == "colmajor"),
+                               extra_opts=opts)
+            torch.cuda.synchronize()
+            assert torch.equal(Ar, Ar2) and torch.equal(brr, br2) and torch.equal(wtu, wtu2), (layout, pname)
+            # skipped samples untouched
+            off = torch.as_tensor(act == 0, device="cuda")
+            assert bool((Ar[off] == -7.0).all()) and bool((brr[off] == -7.0).all())
+            # (i) oracle subset
+            Arh, brh, wtuh = Ar.cpu().numpy(), brr.cpu().numpy(), wtu.cpu().numpy()
+            for b in probe:
+                Wb = Wsh if layout == "shared" else Wps[b]
+                Ar_ref, br_ref = cs.oracle(b, Wb, pname, True)
+                assert rel_l2(Arh[b], Ar_ref) < 1e-13, (layout, pname, b)
+                assert rel_l2(brh[b], br_ref) < 1e-12, (layout, pname, b)
+                assert rel_l2(wtuh[b], Wb.T @ cs.U[b]) < 1e-13
+
+
+@pytest.mark.parametrize("N,r,B", [(512, 40, 1100), (300, 21, 1031), (511, 5, 1050)])
+def test_reduce_lifted_persistent_loop(hip, N, r, B):
+    """bg_rom_reduce_lifted (u = Phi q formed in-kernel, q prefetched by dword LDS DMA) and bg_rom_lift."""
+    from burgers_hip import rom
+    cs = _Case(N, B, 77 * N + r)
+    rng = cs.rng
+    Phi = np.linalg.qr(rng.standard_normal((N, r)))[0]
+    q = rng.standard_normal((B, r)) * 3.0
+    act = _holes(B, rng); actd = _dev(act)
+    Phid, qd = _dev(Phi), _dev(q)
+    Ulift = q @ Phi.T
+    probe = [b for b in np.linspace(0, B - 1, 7).astype(int) if act[b]]
+    for pname, proj in (("galerkin", 0), ("lspg", 1)):
+        Ar, brr, wtu = _outs(B, r)
+        Uo = torch.full((B, N), -7.0, dtype=torch.float64, device="cuda")
+        rom.rom_reduce_lifted(cs.c, Phid, qd, Uo, cs.G, proj, True, actd, Ar, brr, wtu)
+        Ar2, br2, wtu2 = _outs(B, r)
+        Uo2 = torch.full((B, N), -7.0, dtype=torch.float64, device="cuda")
+        for lo in range(0, B, CHUNK):
+            hi = min(B, lo + CHUNK)
+            rom.rom_reduce_lifted(cs.sub(lo, hi), Phid, qd[lo:hi], Uo2[lo:hi], cs.G[lo:hi], proj, True, actd[lo:hi],
+                                  Ar2[lo:hi], br2[lo:hi], wtu2[lo:hi])
+        torch.cuda.synchronize()
+        assert torch.equal(Ar, Ar2) and torch.equal(brr, br2) and torch.equal(wtu, wtu2) and torch.equal(Uo, Uo2)
+        Uh, Arh, brh = Uo.cpu().numpy(), Ar.cpu().numpy(), brr.cpu().numpy()
+        assert np.abs(Uh[act == 1] - Ulift[act == 1]).max() < 1e-12
+        assert (Uh[act == 0] == -7.0).all()
+        for b in probe:
+            Ar_ref, br_ref = cs.oracle(b, Phi, pname, True, U=Ulift[b])
+            assert rel_l2(Arh[b], Ar_ref) < 1e-12 and rel_l2(brh[b], br_ref) < 1e-11, (pname, b)
+    Uo = torch.full((B, N), -7.0, dtype=torch.float64, device="cuda")
+    rom.rom_lift(cs.c, Phid, qd, Uo, actd)
+    torch.cuda.synchronize()
+    Uh = Uo.cpu().numpy()
+    assert np.abs(Uh[act == 1] - Ulift[act == 1]).max() < 1e-12 and (Uh[act == 0] == -7.0).all()
+
+
+@pytest.mark.parametrize("N,r,B", [(512, 30, 1100), (301, 16, 1040)])
+def test_reduce_indexed_mixed_blocks(hip, N, r, B):
+    """bg_rom_reduce_indexed with a mixed w_index: runs of equal blocks (fragments kept) and changes of
+    block from one sample of a workgroup to its next (fragments reloaded), holes in between."""
+    from burgers_hip import rom
+    cs = _Case(N, B, 5 * N + r)
+    rng = cs.rng
+    C = 5
+    stack = rng.standard_normal((C, N, r))
+    widx = rng.integers(0, C, B).astype(np.int32)
+    widx[256:512] = widx[0:256]                      # second sample of every workgroup: same block as the first
+    widx[512:768] = (widx[0:256] + 1) % C            # third: a different one
+    act = _holes(B, rng); actd = _dev(act)
+    stackd, widxd = _dev(stack), _dev(widx)
+    probe = [b for b in np.linspace(0, B - 1, 9).astype(int) if act[b]]
+    for pname, proj in (("galerkin", 0), ("lspg", 1)):
+        Ar, brr, wtu = _outs(B, r)
+        rom.rom_reduce(cs.c, stackd, cs.Ud, cs.G, proj, True, actd, Ar, brr, wtu, w_index=widxd)
+        Ar2, br2, wtu2 = _outs(B, r)
+        for lo in range(0, B, CHUNK):
+            hi = min(B, lo + CHUNK)
+            rom.rom_reduce(cs.sub(lo, hi), stackd, cs.Ud[lo:hi], cs.G[lo:hi], proj, True, actd[lo:hi], Ar2[lo:hi],
+                           br2[lo:hi], wtu2[lo:hi], w_index=widxd[lo:hi].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(Ar, Ar2) and torch.equal(brr, br2) and torch.equal(wtu, wtu2)
+        Arh, brh = Ar.cpu().numpy(), brr.cpu().numpy()
+        for b in probe:
+            Ar_ref, br_ref = cs.oracle(b, stack[widx[b]], pname, True)
+            assert rel_l2(Arh[b], Ar_ref) < 1e-13 and rel_l2(brh[b], br_ref) < 1e-12, (pname, b)
+
+
+def _to_frag(hip, W, N, r):
+    """(B, N, r) -> the fragment-major layout of bg_quad_tangent / bg_rom_reduce_frag:
+    element (row o*S + s, col 4c + t) of sample b at ((c*S + s)*64 + o)*4 + t."""
+    B = W.shape[0]
+    NP = int(hip.load().bg_rom_frag_pad(r)); NB = NP // 4
+    per = int(hip.load().bg_rom_frag_elems(N, r)); S = per // (NB * 256)
+    Wp = torch.zeros((B, 64 * S, NP), dtype=torch.float64, device=W.device)
+    Wp[:, :N, :r] = W
+    return Wp.reshape(B, 64, S, NB, 4).permute(0, 3, 2, 1, 4).contiguous().reshape(B, per)
+
+
+@pytest.mark.parametrize("N,r,B", [(512, 40, 1030), (256, 21, 1100), (500, 8, 1040)])
+def test_reduce_frag_layout_persistent_loop(hip, N, r, B):
+    """bg_rom_reduce_frag (the layout the quadratic-manifold tangent kernel writes) gives the bits of the
+    row-major per-sample layout, over a persistent loop with holes."""
+    from burgers_hip import lib as L_, rom
+    cs = _Case(N, B, 3 * N + r)
+    rng = cs.rng
+    W = _dev(rng.standard_normal((B, N, r)))
+    Wf = _to_frag(L_, W, N, r)
+    act = _holes(B, rng); actd = _dev(act)
+    c = cs.c
+    for proj in (0, 1):
+        Ar, brr, wtu = _outs(B, r)
+        rom.rom_reduce(c, W, cs.Ud, cs.G, proj, False, actd, Ar, brr, wtu)
+        Ar2, br2, wtu2 = _outs(B, r)
+        with torch.cuda.device(c.device):
+            L_.check(c.L.bg_rom_reduce_frag(N, B, r, proj, L_.ptr(c.X), L_.ptr(Wf), L_.ptr(cs.Ud), L_.ptr(cs.G),
+                                           L_.ptr(c.hfs), L_.ptr(c.mu1), c.dt, c.E, c.mesh_opt, L_.ptr(actd), L_.ptr(Ar2),
+                                           L_.ptr(br2), L_.ptr(wtu2), c.stream()), "bg_rom_reduce_frag")
+        torch.cuda.synchronize()
+        assert torch.equal(Ar, Ar2) and torch.equal(brr, br2) and torch.equal(wtu, wtu2)
+
+
+def test_quad_tangent_many_chunks(hip):
+    """bg_quad_tangent over more than one 64-sample chunk, at config 4's shape (n = 40): against
+    T = Phi + H3 . q formed by a GEMM, in the fragment-major layout."""
+    from burgers_hip import lib as L_, rom
+    N, n, B = 512, 40, 1030
+    rng = np.random.default_rng(8)
+    L = L_.load()
+    Phi = _dev(rng.standard_normal((N, n)))
+    H3 = _dev(rng.standard_normal((N, n, n)))
+    q = _dev(rng.standard_normal((B, n)))
+    NP = int(L.bg_rom_frag_pad(n)); per = int(L.bg_rom_frag_elems(N, n))
+    H3p = torch.nn.functional.pad(H3, (0, NP - n)).contiguous()
+    qp = torch.nn.functional.pad(q, (0, NP - n)).contiguous()
+    act = _holes(B, rng); actd = _dev(act)
+    Wf = torch.full((B, per), -7.0, dtype=torch.float64, device="cuda")
+    L_.check(L.bg_quad_tangent(N, B, n, L_.ptr(Phi), L_.ptr(H3p), L_.ptr(qp), L_.ptr(actd), L_.ptr(Wf),
+                               L_.stream_ptr(torch.device("cuda", 0))), "bg_quad_tangent")
+    T = Phi.unsqueeze(0) + torch.einsum("iac,bc->bia", H3, q)
+    ref = _to_frag(L_, T, N, n)
+    torch.cuda.synchronize()
+    on = torch.as_tensor(act == 1, device="cuda")
+    assert float((Wf[on] - ref[on]).abs().max()) < 1e-12 * float(ref.abs().max())
+    assert bool((Wf[~on] == -7.0).all())
+
+
+def test_lu_solve_update_large_batch(hip):
+    """bg_lu_solve_update over 4100 systems (more than one wave per SIMD): solution vs numpy, update rules and
+    the still-active counter, all three modes."""
+    from burgers_hip import rom
+    rng = np.random.default_rng(12)
+    B, n = 4100, 40
+    A = rng.standard_normal((B, n, n)) + 6.0 * np.eye(n)
+    b = rng.standard_normal((B, n))
+    base = rng.standard_normal((B, n))
+    dq_ref = np.linalg.solve(A, -b[..., None])[..., 0]
+    bound = 1e-13 * np.maximum(10.0, np.linalg.cond(A))          # per-sample, condition-scaled (as test_lu_solve_vs_numpy)
+    L = hip.load()
+    Ad, bd = _dev(A), _dev(b)
+    for mode in (1, 2, 3):
+        act = _dev(_holes(B, rng))
+        act0 = act.clone()
+        q = _dev(base.copy()); wtu = _dev(base.copy()) if mode == 1 else None
+        dq = torch.zeros((B, n), dtype=torch.float64, device="cuda")
+        k = torch.zeros(B, dtype=torch.int32, device="cuda"); fl = torch.zeros_like(k); info = torch.zeros_like(k)
+        counter = torch.zeros((2, hip.BG_COUNTER_SLOTS * hip.BG_COUNTER_STRIDE), dtype=torch.int32, device="cuda")
+        hip.check(L.bg_lu_solve_update(n, B, hip.ptr(Ad), hip.ptr(bd), mode, hip.ptr(wtu) if wtu is not None else None,
+                                       hip.ptr(q), hip.ptr(dq), 0.5, 20, hip.ptr(act), hip.ptr(k), hip.ptr(fl), hip.ptr(counter),
+                                       hip.ptr(info), hip.stream_ptr(torch.device("cuda", 0))), "bg_lu_solve_update")
+        torch.cuda.synchronize()
+        on = act0.cpu().numpy() == 1
+        rel = np.linalg.norm(dq.cpu().numpy() - dq_ref, axis=1) / np.linalg.norm(dq_ref, axis=1)
+        assert (rel[on] < bound[on]).all(), float((rel[on] / bound[on]).max())
+        qn = base + dq_ref
+        relq = np.linalg.norm(q.cpu().numpy() - qn, axis=1) / np.linalg.norm(qn, axis=1)
+        assert (relq[on] < bound[on] * 10).all() and np.array_equal(q.cpu().numpy()[~on], base[~on])
+        nd, nq = np.linalg.norm(dq_ref, axis=1), np.linalg.norm(qn, axis=1)
+        err = nd / nq if mode == 1 else (nd / np.maximum(1e-14, nq) if mode == 2 else nd / (nq + 1e-14))
+        more = (err > 0.5) if mode != 2 else ~(err < 0.5)
+        clear = np.abs(err - 0.5) > 1e-6                             # away from the threshold the decision is exact
+        assert np.array_equal(act.cpu().numpy()[on & clear], more[on & clear].astype(np.int32))
+        assert np.array_equal(k.cpu().numpy(), on.astype(np.int32))
+        assert int(counter[0].sum().item()) == int(act.sum().item()) and int(counter[1].sum().item()) == 0
+
+
+# --------------------------------------------------------------------------- full steppers
+def _chunked(run, B, chunk=CHUNK):
+    outs = [run(lo, min(B, lo + chunk)) for lo in range(0, B, chunk)]
+    return (torch.cat([o.hist for o in outs]), torch.cat([o.iters for o in outs]), torch.cat([o.flags for o in outs]))
+
+
+def test_config3_pod_prom_b4096(hip):
+    """BASELINE configs[2]: POD-Galerkin / LSPG, r = 40, 4096 samples, N = 512 (a few time steps): bitwise
+    equal to 200-sample chunks, oracle on a strided subset, iteration counts identical."""
+    from burgers_hip import rom
+    g = load_golden("committed_pod_r40.npz")
+    rng = np.random.default_rng(20251121)
+    X, _ = mesh(512)
+    B, nT = 4096, 6
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    for proj in ("Galerkin", "LSPG"):
+        res = rom.pod_prom_run(X, np.ones(512), mu1, mu2, 0.05, nT, g["Phi"], projection=proj)
+        h2, it2, fl2 = _chunked(lambda lo, hi: rom.pod_prom_run(X, np.ones(512), mu1[lo:hi], mu2[lo:hi], 0.05, nT, g["Phi"],
+                                                                projection=proj), B)
+        torch.cuda.synchronize()
+        assert torch.equal(res.iters, it2) and torch.equal(res.flags, fl2) and torch.equal(res.hist, h2), proj
+        assert int(res.flags.abs().sum().item()) == 0
+        for b in np.linspace(0, B - 1, 6).astype(int):
+            U, ito = br.pod_prom_burgers(X, 0.05, nT, np.ones(512), mu1[b], 0.0, mu2[b], g["Phi"], projection=proj,
+                                         return_iters=True)
+            assert rel_l2(res.hist[b].cpu().numpy().T, U) < TOL, (proj, b)
+            assert np.array_equal(res.iters[b].cpu().numpy(), ito), (proj, b)
+
+
+@pytest.fixture(scope="module")
+def quad_r40(hip):
+    """Phi (512, 40), H (512, 820) from this framework's own training sweep (3 x 3 grid of
+    FEM/paper_training_stage.py:8-10) through pod.build_quadratic_manifold: BASELINE configs[3]."""
+    from burgers_hip import fom, pod
+    N = 512
+    X, _ = mesh(N)
+    m1, m2 = np.meshgrid(np.linspace(4.25, 5.5, 3), np.linspace(0.015, 0.03, 3), indexing="ij")
+    res = fom.fom_run(X, np.ones(N), m1.ravel(), m2.ravel(), 0.05, 500)
+    S = pod.snapshot_matrix(res.hist).contiguous()
+    Phi, H, _ = pod.build_quadratic_manifold(S, 40, alpha=1e-2)
+    torch.cuda.synchronize()
+    return X, Phi.cpu().numpy(), H.cpu().numpy()
+
+
+def test_config4_quadratic_r40_k820(hip, quad_r40):
+    """BASELINE configs[3]: quadratic manifold n = 40 (k = 820), 1024 samples per GPU: quad_tangent_kernel<8,40> +
+    rom_reduce4_kernel<8,10> on per-sample fragment-major tangents, persistent loop.  The decode GEMMs run through
+    rocBLAS, whose summation order may depend on the batch size, so chunks are compared to 1e-11 (not bitwise)."""
+    from burgers_hip import rom
+    X, Phi, H = quad_r40
+    assert Phi.shape == (512, 40) and H.shape == (512, 820)
+    rng = np.random.default_rng(4)
+    B, nT = 1024, 4
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    for proj in ("LSPG", "Galerkin"):
+        res = rom.quadratic_run(X, np.ones(512), mu1, mu2, 0.05, nT, Phi, H, projection=proj)
+        h2, it2, fl2 = _chunked(lambda lo, hi: rom.quadratic_run(X, np.ones(512), mu1[lo:hi], mu2[lo:hi], 0.05, nT, Phi, H,
+                                                                 projection=proj), B)
+        torch.cuda.synchronize()
+        assert torch.equal(res.iters, it2) and torch.equal(res.flags, fl2), proj
+        assert float((res.hist - h2).abs().max()) < 1e-11 * float(h2.abs().max()), proj
+        for b in np.linspace(0, B - 1, 4).astype(int):
+            U, ito = br.pod_quadratic_manifold(X, 0.05, nT, np.ones(512), mu1[b], 0.0, mu2[b], Phi, H, projection=proj,
+                                               return_iters=True)
+            assert rel_l2(res.hist[b].cpu().numpy().T, U) < 1e-9, (proj, b)      # cond(H-augmented tangent) amplifies rounding
+            assert np.array_equal(res.iters[b].cpu().numpy(), ito), (proj, b)
+
+
+def _ann_model(g):
+    import torch.nn as nn
+    dims = [5, 32, 64, 128, 256, 256, 91]
+    layers = []
+    for i in range(6):
+        lin = nn.Linear(dims[i], dims[i + 1])
+        with torch.no_grad():
+            lin.weight.copy_(torch.from_numpy(g[f"W{i}"])); lin.bias.copy_(torch.from_numpy(g[f"b{i}"]))
+        layers.append(lin)
+        if i < 5:
+            layers.append(nn.ELU())
+    return nn.Sequential(*layers).eval()
+
+
+def test_config5_pod_ann_b2048(hip):
+    """BASELINE configs[4], intrusive form: POD-ANN n = 5, nbar = 91, 2048 samples per GPU (column-major per-sample
+    tangents through the persistent loop).  fp32 MLP: tolerances as in test_pod_ann_live_reference (5e-6)."""
+    from burgers_hip import rom
+    g = load_golden("ann_n5.npz")
+    model = _ann_model(g)
+    X, _ = mesh(512)
+    rng = np.random.default_rng(6)
+    B, nT = 2048, 3
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    res = rom.pod_ann_run(X, np.ones(512), mu1, mu2, 0.05, nT, g["U_p"], g["U_s"], model)
+    h2, it2, fl2 = _chunked(lambda lo, hi: rom.pod_ann_run(X, np.ones(512), mu1[lo:hi], mu2[lo:hi], 0.05, nT, g["U_p"], g["U_s"],
+                                                           model), B)
+    torch.cuda.synchronize()
+    err = (res.hist - h2).flatten(1).norm(dim=1) / h2.flatten(1).norm(dim=1)
+    assert float(err.max()) < 5e-6
+    Ws = [g[f"W{i}"] for i in range(6)]; bs = [g[f"b{i}"] for i in range(6)]
+    for b in np.linspace(0, B - 1, 4).astype(int):
+        Uo = br.pod_ann_prom(X, 0.05, nT, np.ones(512), mu1[b], 0.0, mu2[b], g["U_p"], g["U_s"], Ws, bs)
+        assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < 5e-6, b
+
+
+def test_local_prom_b1200(hip):
+    """local_prom_burgers over 1200 samples: per-sample cluster index through bg_rom_reduce_indexed's persistent loop."""
+    from burgers_hip import rom
+    g = load_golden("local_pod.npz")
+    X, _ = mesh(512)
+    bases = {c: g[f"basis{c}"] for c in range(4)}
+    rng = np.random.default_rng(9)
+    B, nT = 1200, 5
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    cl = (g["centers"], bases, g["U_global"], 12)
+    for proj in ("Galerkin", "LSPG"):
+        res = rom.local_prom_run(X, np.ones(512), mu1, mu2, 0.05, nT, *cl, projection=proj)
+        h2, it2, fl2 = _chunked(lambda lo, hi: rom.local_prom_run(X, np.ones(512), mu1[lo:hi], mu2[lo:hi], 0.05, nT, *cl,
+                                                                  projection=proj), B)
+        torch.cuda.synchronize()
+        assert torch.equal(res.iters, it2) and torch.equal(res.flags, fl2)
+        assert float((res.hist - h2).abs().max()) < 1e-11 * float(h2.abs().max())
+        for b in np.linspace(0, B - 1, 4).astype(int):
+            Uo, ito, _ = br.local_prom_burgers(X, 0.05, nT, np.ones(512), mu1[b], 0.0, mu2[b], *cl, projection=proj,
+                                               return_iters=True)
+            assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < TOL and np.array_equal(res.iters[b].cpu().numpy(), ito)
