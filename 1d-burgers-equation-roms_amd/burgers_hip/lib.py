@@ -27,7 +27,7 @@ BG_ERR_PROJECTION = -6
 BG_ERR_WORKSPACE = -7
 BG_PROJ_GALERKIN, BG_PROJ_LSPG = 0, 1
 BG_FLAG_HIT_CAP, BG_FLAG_NONFINITE = 1, 2
-BG_OPT_SUPG, BG_OPT_NONUNIFORM, BG_OPT_W_COLMAJOR, BG_OPT_MFMA_16X16 = 1, 2, 4, 8
+BG_OPT_SUPG, BG_OPT_NONUNIFORM, BG_OPT_W_COLMAJOR, BG_OPT_MFMA_16X16, BG_OPT_FORCE_PIVOTED = 1, 2, 4, 8, 16
 BG_ACT_NONE, BG_ACT_ELU, BG_ACT_RELU, BG_ACT_TANH = 0, 1, 2, 3
 BG_COUNTER_SLOTS, BG_COUNTER_STRIDE = 16, 32
 BG_RBF_GAUSSIAN, BG_RBF_IMQ = 0, 1
@@ -71,6 +71,10 @@ _SIGNATURES = {
                                             c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                             c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_int_p,
                                             c_double_p, c_double_p, c_double_p, ctypes.c_void_p]),
+    "bg_rom_run_max_r": (ctypes.c_int, []),
+    "bg_rom_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                  c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
     "bg_rom_lift": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                    c_int_p, c_double_p, ctypes.c_void_p]),
     "bg_rom_frag_elems": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int]),

@@ -250,9 +250,47 @@ def _workspace(c, r):
 
 
 # --------------------------------------------------------------------------- POD
+def pod_prom_run_fused(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E=0.0, tol=1e-6, max_it=20, device=None, options=0):
+    """``pod_prom_burgers`` for a batch with the whole time loop on the device (bg_rom_run): one workgroup per
+    sample, no host in the loop.  Covers N <= 512 and r <= bg_rom_run_max_r()."""
+    L = _lib.load()
+    device = _lib.require_device(device)
+    opts = _lib.mesh_options(check_mesh(X), supg=True) | options
+    Xd = _as_dev(X, device)
+    N = Xd.numel()
+    Phid = _as_dev(Phi, device)
+    if Phid.dim() != 2 or Phid.shape[0] != N:
+        raise ValueError("Phi must have one row per mesh node")
+    r = Phid.shape[1]
+    u0d, mu1d, mu2d = _batch_inputs(u0, mu1, mu2, N, device)
+    B = mu1d.numel()
+    hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
+    iters = torch.zeros((B, nsteps), dtype=torch.int32, device=device)
+    flags = torch.zeros((B,), dtype=torch.int32, device=device)
+    info = torch.zeros((B,), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        rc = L.bg_rom_run(N, B, r, int(nsteps), proj, _lib.ptr(Xd), _lib.ptr(Phid), _lib.ptr(u0d), _lib.ptr(mu1d),
+                          _lib.ptr(mu2d), float(dt), float(E), float(tol), int(max_it), int(opts), _lib.ptr(hist),
+                          _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(info), _lib.stream_ptr(device))
+    _lib.check(rc, "bg_rom_run")
+    res = FomResult(hist, iters, flags)
+    res.info = info              # checked lazily by the facade (a readback would synchronise)
+    return res
+
+
+def check_singular(res):
+    """np.linalg.solve raises LinAlgError('Singular matrix') at :767; the device loop records it per sample."""
+    info = getattr(res, "info", None)
+    if info is not None and bool(info.ne(0).any()):
+        raise SingularReducedSystem("Singular matrix")
+    return res
+
+
 def pod_prom_run(X, u0, mu1, mu2, dt, nsteps, Phi, projection="Galerkin", E=0.0, tol=1e-6, max_it=20,
-                 device=None):
-    """Batched ``pod_prom_burgers``; ``projection`` is case-sensitive like the reference (:754-764)."""
+                 device=None, fused=True):
+    """Batched ``pod_prom_burgers``; ``projection`` is case-sensitive like the reference (:754-764).
+    ``fused`` (default): the device-side time loop bg_rom_run where it applies (N <= 512, r <= 40); otherwise, or
+    with ``fused=False``, the batched iteration bg_rom_reduce -> bg_lu_solve_update driven from the host."""
     if projection not in ("Galerkin", "LSPG"):
         raise ValueError(f"Projection method '{projection}' is not available. Please use 'Galerkin' or 'LSPG'.")
     proj = PROJ[projection.lower()]
@@ -260,6 +298,8 @@ def pod_prom_run(X, u0, mu1, mu2, dt, nsteps, Phi, projection="Galerkin", E=0.0,
     r_in, n_in = np.shape(Phi)[1], np.shape(Phi)[0]
     if r_in > L.bg_rom_max_r() or n_in > L.bg_rom_max_n():
         return _pod_prom_run_library(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E, tol, max_it, device)
+    if fused and r_in <= L.bg_rom_run_max_r():
+        return check_singular(pod_prom_run_fused(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E, tol, max_it, device))
     c = _setup(X, u0, mu1, mu2, dt, E, device)
     Phid = _as_dev(Phi, c.device)
     if Phid.shape[0] != c.N:

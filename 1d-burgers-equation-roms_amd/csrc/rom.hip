@@ -15,7 +15,7 @@
 
 #include "../../include/burgers_hip.h"
 #include "abi_common.hpp"
-#include "fom_device.hpp"
+#include "rom_device.hpp"
 
 namespace {
 
@@ -193,44 +193,13 @@ __global__ __launch_bounds__(256, 1) void rom_reduce_kernel(ReduceArgs a)
         if (a.lift_only) continue;           // workgroup-uniform
         const double mu1 = a.mu1[smp];
         for (int i = tid; i < NPAD; i += 256) {
-            double lo = 0.0, di = 1.0, up = 0.0, rhs = 0.0;
-            if (i < N) {
-                const double um = s_u[i], u0 = s_u[i + 1], ur = s_u[i + 2];
-                const double gi = a.G[(size_t)smp * N + i];
-                double aoffL = mc.aoff, aoffR = mc.aoff, ddL = mc.dd1, ddR = mc.dd1;
-                if (a.nonuniform && i > 0) {                          // per-element lengths
-                    const double hl = a.x[i] - a.x[i - 1];
-                    aoffL = hl / 6.0 - a.dt * a.E / hl; ddL = hl / 3.0 + a.dt * a.E / hl;
-                    if (i < N - 1) {
-                        const double hr = a.x[i + 1] - a.x[i];
-                        aoffR = hr / 6.0 - a.dt * a.E / hr; ddR = hr / 3.0 + a.dt * a.E / hr;
-                    }
-                }
-                if (i == 0) {
-                    rhs = mu1 - u0;                                   // Dirichlet row
-                } else {
-                    // left element (i-1, i)
-                    const double wl = um + u0;
-                    lo = __builtin_fma(-mc.dt6, wl + u0, aoffL);
-                    const double tl = __builtin_fma(wl, u0 - um, -a.hfs[(size_t)smp * N + i - 1]);
-                    const double sl = tl * rcp(fmax(fabs(wl), 2.0e-10));
-                    double b = __builtin_fma(-mc.kap, sl, gi);
-                    if (i < N - 1) {
-                        const double wr = u0 + ur;
-                        up = __builtin_fma(mc.dt6, wr + u0, aoffR);
-                        di = __builtin_fma(mc.dt6, um - ur, ddL + ddR);
-                        const double tr = __builtin_fma(wr, ur - u0, -a.hfs[(size_t)smp * N + i]);
-                        const double sr = tr * rcp(fmax(fabs(wr), 2.0e-10));
-                        b = __builtin_fma(mc.kap, sr, b);
-                    } else {
-                        di = __builtin_fma(mc.dt6, wl + u0, ddL);
-                    }
-                    rhs = __builtin_fma(-lo, um, b);
-                    rhs = __builtin_fma(-di, u0, rhs);
-                    rhs = __builtin_fma(-up, ur, rhs);
-                }
-            }
-            s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = -rhs;  // [3] = R
+            double lo, di, up, R;
+            const bool in = i < N;
+            rom_assemble_row(i, N, s_u[i], s_u[i + 1], s_u[i + 2], in ? a.G[(size_t)smp * N + i] : 0.0,
+                             (in && i > 0) ? a.hfs[(size_t)smp * N + i - 1] : 0.0,
+                             (in && i < N - 1) ? a.hfs[(size_t)smp * N + i] : 0.0, mu1, mc, a.nonuniform, a.x, a.dt, a.E,
+                             lo, di, up, R);
+            s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = R;
         }
         __syncthreads();
         // ---- MFMA contraction over this wave's rows -------------------------------------------
@@ -458,43 +427,14 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
         // ---- assembly into LDS (same arithmetic as rom_reduce_kernel) -----------------------
         const double mu1 = a.mu1[smp];
         for (int i = tid; i < NPAD; i += 256) {
-            double lo = 0.0, di = 1.0, up = 0.0, rhs = 0.0;
-            if (i < N) {
-                const double um = s_u[buf][i + 1], u0 = s_u[buf][i + 2], ur = (i + 1 < N) ? s_u[buf][i + 3] : 0.0;
-                const double gi = pref ? s_g[buf][i] : a.G[(size_t)smp * N + i];
-                double aoffL = mc.aoff, aoffR = mc.aoff, ddL = mc.dd1, ddR = mc.dd1;
-                if (a.nonuniform && i > 0) {
-                    const double hl = a.x[i] - a.x[i - 1];
-                    aoffL = hl / 6.0 - a.dt * a.E / hl; ddL = hl / 3.0 + a.dt * a.E / hl;
-                    if (i < N - 1) {
-                        const double hr = a.x[i + 1] - a.x[i];
-                        aoffR = hr / 6.0 - a.dt * a.E / hr; ddR = hr / 3.0 + a.dt * a.E / hr;
-                    }
-                }
-                if (i == 0) {
-                    rhs = mu1 - u0;
-                } else {
-                    const double wl = um + u0;
-                    lo = __builtin_fma(-mc.dt6, wl + u0, aoffL);
-                    const double tl = __builtin_fma(wl, u0 - um, -(pref ? s_h[buf][i - 1] : a.hfs[(size_t)smp * N + i - 1]));
-                    const double sl = tl * rcp(fmax(fabs(wl), 2.0e-10));
-                    double b = __builtin_fma(-mc.kap, sl, gi);
-                    if (i < N - 1) {
-                        const double wr = u0 + ur;
-                        up = __builtin_fma(mc.dt6, wr + u0, aoffR);
-                        di = __builtin_fma(mc.dt6, um - ur, ddL + ddR);
-                        const double tr = __builtin_fma(wr, ur - u0, -(pref ? s_h[buf][i] : a.hfs[(size_t)smp * N + i]));
-                        const double sr = tr * rcp(fmax(fabs(wr), 2.0e-10));
-                        b = __builtin_fma(mc.kap, sr, b);
-                    } else {
-                        di = __builtin_fma(mc.dt6, wl + u0, ddL);
-                    }
-                    rhs = __builtin_fma(-lo, um, b);
-                    rhs = __builtin_fma(-di, u0, rhs);
-                    rhs = __builtin_fma(-up, ur, rhs);
-                }
-            }
-            s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = -rhs;   // [3] = R
+            double lo, di, up, R;
+            const bool in = i < N;
+            const double gi = in ? (pref ? s_g[buf][i] : a.G[(size_t)smp * N + i]) : 0.0;
+            const double hL = (in && i > 0) ? (pref ? s_h[buf][i - 1] : a.hfs[(size_t)smp * N + i - 1]) : 0.0;
+            const double hR = (in && i < N - 1) ? (pref ? s_h[buf][i] : a.hfs[(size_t)smp * N + i]) : 0.0;
+            rom_assemble_row(i, N, s_u[buf][i + 1], s_u[buf][i + 2], (i + 1 < N) ? s_u[buf][i + 3] : 0.0, gi, hL, hR, mu1, mc,
+                             a.nonuniform, a.x, a.dt, a.E, lo, di, up, R);
+            s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = R;
         }
         __syncthreads();
         if (pref && nxt < a.B) prefetch(nxt, buf ^ 1);           // streams in under the MFMA phase
@@ -666,26 +606,6 @@ struct LuArgs {
     int32_t* counter;     // [2 * BG_COUNTER_SLOTS * BG_COUNTER_STRIDE]  partial counts: still active | singular (see burgers_hip.h)
 };
 
-__device__ __forceinline__ double readlane_f64(double v, int srclane)
-{
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
-{
-    // DPP butterfly on 32-bit keys; result valid in lane 63, then broadcast
-    unsigned t;
-    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); v = v > t ? v : t;
-    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true); v = v > t ? v : t;
-    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); v = v > t ? v : t;
-    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true); v = v > t ? v : t;
-    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true); v = v > t ? v : t;
-    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true); v = v > t ? v : t;
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 template <int NMAX>
 __global__ __launch_bounds__(256) void lu_solve_kernel(LuArgs a)
 {
@@ -702,35 +622,8 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(LuArgs a)
         row[j] = (lane < n && j < n) ? Ap[(size_t)lane * n + j] : ((lane == j) ? 1.0 : 0.0);
     row[NMAX] = (lane < n) ? a.sign * a.b[(size_t)sys * n + lane] : 0.0;
 
-    bool used = false;        // this lane's row already served as a pivot row
-    int my_step = -1;         // elimination step at which it did
-    int info = 0;
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-        // pivot search on the high dword of |a[k]| (monotone for non-negative doubles)
-        unsigned key = used ? 0u : (((unsigned)__double2hiint(row[k]) & 0x7fffffffu) + 1u);
-        const unsigned best = wave_max_u32(key);
-        const unsigned long long m = __ballot(key == best && !used);
-        const int p = __builtin_ctzll(m);                       // lowest candidate lane
-        const double piv = readlane_f64(row[k], p);
-        if (piv == 0.0 && info == 0) info = k + 1;
-        const double rp = rcp(piv);
-        const bool is_p = lane == p;
-        const double mult = (used || is_p) ? 0.0 : row[k] * rp;
-#pragma unroll
-        for (int j = k + 1; j <= NMAX; ++j) row[j] = __builtin_fma(-mult, readlane_f64(row[j], p), row[j]);
-        if (is_p) { used = true; my_step = k; }
-    }
-    // back substitution, column oriented: the row that pivoted at step k holds U[k][*]
-    double xout = 0.0;
-#pragma unroll
-    for (int k = NMAX - 1; k >= 0; --k) {
-        const unsigned long long m = __ballot(my_step == k);
-        const int p = __builtin_ctzll(m);
-        const double xk = readlane_f64(row[NMAX], p) * rcp(readlane_f64(row[k], p));
-        row[NMAX] = (my_step < k) ? __builtin_fma(-row[k], xk, row[NMAX]) : row[NMAX];
-        xout = (lane == k) ? xk : xout;
-    }
+    int info;
+    const double xout = lu_pivoted_wave<NMAX>(row, lane, info);
     if (lane < n) a.x[(size_t)sys * n + lane] = xout;
     if (lane == 0 && a.info && info) a.info[sys] = info;
     if (a.mode != 0) {

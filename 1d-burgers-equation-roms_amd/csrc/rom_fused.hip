@@ -1,0 +1,459 @@
+// rom_fused.hip -- the whole POD-PROM time loop of one sample on one compute unit, and its C-ABI entry point.
+//
+// Replaces FEMBurgers.pod_prom_burgers (reference FEM/fem_burgers.py:709-785) for a batch of samples: one 256-thread
+// workgroup owns a sample for ALL time steps and ALL Picard iterations.  The basis fragments stay in registers, u, g,
+// the per-sample load constants, the reduced system and q stay in LDS; HBM sees the initial state once and one
+// N-row history write per time step.  Per iteration, with no kernel boundary and no host in between:
+//     assembly (2 rows per thread)  ->  fp64 MFMA projection (v_mfma_f64_4x4x4_4b, as rom_reduce4_kernel)
+//     ->  r x r solve by all four waves (below)  ->  q = Phi^T u + dq, error, stopping test  ->  lift u = Phi q.
+//
+// The reduced solve.  np.linalg.solve (:767) is LU with partial pivoting.  On these systems (cond(Ar) < 10 on the
+// reference's bases) LAPACK never leaves the diagonal, so the kernel eliminates WITHOUT a pivot search and watches
+// the multipliers: as long as every |l_ik| <= 1 the diagonal was the column maximum at every step, i.e. the
+// operations are the ones partial pivoting performs.  If one multiplier exceeds 1 (or a pivot is 0 / not finite)
+// the system is solved again by the pivoted single-wave routine lu_pivoted_wave -- same semantics as bg_lu_solve.
+// The unpivoted elimination is spread over the four waves: lane = row, wave w owns the 4-column blocks
+// b = w, w+4, w+8 (the right-hand side rides with wave 3); the owner of panel p factors it in its own registers
+// (no communication inside a panel), publishes the four multiplier vectors through LDS, and every wave applies them
+// to its own columns with v_readlane broadcasts of the pivot rows.  The owner of panel p+1 updates that block first
+// and factors it while the others are still applying panel p (look-ahead): one barrier per panel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/burgers_hip.h"
+#include "abi_common.hpp"
+#include "rom_device.hpp"
+
+namespace {
+
+using namespace bg;
+
+struct RomRunArgs {
+    const double* x;        // [N]
+    const double* Phi;      // [N][r]
+    const double* u0;       // [B][N]
+    const double* mu1;      // [B]
+    const double* mu2;      // [B]
+    double* hist;           // [B][nsteps+1][N]
+    int32_t* iters;         // [B][nsteps]
+    int32_t* flags;         // [B]
+    int32_t* info;          // [B]
+    double dt, E, tol;
+    int N, B, r, nsteps, max_it, supg, nonuniform, force_pivoted;
+};
+
+// ---- one MFMA pass over this wave's rows: pairs (ca, cb) with ca in [CA0, CA1) ---------------------------------
+// Same operand layout, accumulation order and block-partial summation as rom_reduce4_kernel (rom.hip), so the
+// reduced system has the bits of the batched path.
+template <int S, int NB, bool GAL, int CA0, int CA1, int RW>
+__device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S + 2], const double (*__restrict__ s_coef)[4],
+                                          const double* __restrict__ s_u, int rowbase, int t, int w, int lane,
+                                          double (*__restrict__ s_red)[RW][RW + 4], double (*__restrict__ s_wtu)[RW])
+{
+    constexpr int NACC = GAL ? (CA1 - CA0) * (NB + 1) : NB * (NB + 1) / 2 + NB + NB;
+    double acc[NACC];
+#pragma unroll
+    for (int p = 0; p < NACC; ++p) acc[p] = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = rowbase + s;
+        const double lo = s_coef[i][0], di = s_coef[i][1], up = s_coef[i][2], R = s_coef[i][3];
+        const double ui = s_u[i + 2];
+        double Y[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            double y = lo * frag[c][s];
+            y = __builtin_fma(di, frag[c][s + 1], y);
+            y = __builtin_fma(up, frag[c][s + 2], y);
+            Y[c] = y;
+        }
+        const double X = (t == 0) ? R : ((t == 1) ? ui : 0.0);      // extra B block [R, u, 0, 0]
+        int p = 0;
+        if constexpr (GAL) {
+#pragma unroll
+            for (int ca = CA0; ca < CA1; ++ca) {
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb, ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s + 1], Y[cb], acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s + 1], X, acc[p], 0, 0, 0);
+                ++p;
+            }
+        } else {
+#pragma unroll
+            for (int ca = 0; ca < NB; ++ca) {
+#pragma unroll
+                for (int cb = ca; cb < NB; ++cb, ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(Y[ca], Y[cb], acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(Y[ca], X, acc[p], 0, 0, 0);
+                ++p;
+            }
+#pragma unroll
+            for (int ca = 0; ca < NB; ++ca, ++p)
+                acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s + 1], X, acc[p], 0, 0, 0);
+        }
+    }
+    // sum the four block partials of every pair (lanes differing in bits 2..3), park them per wave in LDS
+    const int oi = lane >> 4, oj = lane & 3;
+    const bool writer = ((lane >> 2) & 3) == 3;
+    const int wslot = writer ? w : 4;            // idle lanes store into the dump slab: no branches
+    int p = 0;
+#pragma unroll
+    for (int ca = (GAL ? CA0 : 0); ca < (GAL ? CA1 : NB); ++ca) {
+#pragma unroll
+        for (int cb = (GAL ? 0 : ca); cb <= NB; ++cb, ++p) {
+            double v = acc[p];
+            v += dpp_mov<0x114>(v);          // row_shr:4
+            v += dpp_mov<0x118>(v);          // row_shr:8 -> lanes with blk == 3 hold the sum
+            s_red[wslot][4 * ca + oi][4 * cb + oj] = v;
+        }
+    }
+    if constexpr (!GAL) {
+#pragma unroll
+        for (int ca = 0; ca < NB; ++ca, ++p) {
+            double v = acc[p];
+            v += dpp_mov<0x114>(v);
+            v += dpp_mov<0x118>(v);
+            s_wtu[(writer && oj == 1) ? w : 4][4 * ca + oi] = v;
+        }
+    }
+}
+
+// ---- cooperative unpivoted elimination (see the file header) ----------------------------------------------------
+template <int NB>
+struct LuRegs {
+    static constexpr int NSLOT = (NB + 3) / 4;
+    double col[NSLOT][4];     // slot s = column block w + 4 s
+    double rhs;               // wave 3 only
+};
+
+template <int NB>
+__device__ __forceinline__ void lu_apply_block(double (&c)[4], const double (&m)[4], int p)
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) c[t] = __builtin_fma(-m[kk], readlane_f64(c[t], 4 * p + kk), c[t]);
+}
+
+// factor the panel held in c[0..3] (columns 4p .. 4p+3, pivots in lanes 4p .. 4p+3); multipliers -> sm[kk][lane]
+__device__ __forceinline__ void lu_factor_panel(double (&c)[4], int p, int lane, double (*__restrict__ sm)[64], bool& bad)
+{
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * p + kk;
+        const double piv = readlane_f64(c[kk], k);
+        const double rp = rcp(piv);
+        const double m = (lane > k) ? c[kk] * rp : 0.0;
+        bad = bad || !(fabs(m) <= 1.0) || !(piv - piv == 0.0) || piv == 0.0;
+#pragma unroll
+        for (int jj = kk + 1; jj < 4; ++jj) c[jj] = __builtin_fma(-m, readlane_f64(c[jj], k), c[jj]);
+        sm[kk][lane] = m;
+    }
+}
+
+template <int S, int NB, int PROJ>
+__global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
+{
+    constexpr int NPAD = 64 * S;
+    constexpr int RW = 4 * NB;                   // padded reduced dimension
+    constexpr bool GAL = PROJ == BG_PROJ_GALERKIN;
+    constexpr int NSLOT = LuRegs<NB>::NSLOT;
+    __shared__ double s_u[NPAD + 4];             // u at offset 2, zero halo on each side
+    __shared__ double s_g[NPAD];                 // M u^n + dt F of the current time step
+    __shared__ double s_h[NPAD];                 // hfs: h_e (f(gp1) + f(gp2)) per element
+    __shared__ double s_fdt[NPAD];               // dt F
+    __shared__ double s_coef[NPAD][4];
+    __shared__ double s_red[5][RW][RW + 4];      // per-wave  Ar | [br, W^T u (Galerkin), 0, 0]; [4] = dump for idle lanes
+    __shared__ double s_wtu[5][RW];              // per-wave  W^T u (LSPG); [4] = dump
+    __shared__ double s_m[2][4][64];             // multipliers of the current / next panel
+    __shared__ double s_U[RW][RW + 1];           // eliminated system: U | y
+    __shared__ double s_q[RW];
+    __shared__ double s_x[RW];                   // solution of the pivoted fallback
+    __shared__ int s_bad[4];
+    __shared__ int s_info;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int t = lane & 3, owner = 16 * w + (lane >> 2);
+    const int N = a.N, r = a.r;
+    const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
+    const MeshConst mc = make_mesh_const(h, a.dt, a.E, a.supg);
+    const int rowbase = owner * S;
+
+    // ---- basis fragments: loaded once per workgroup, kept in registers for every sample ------------------------
+    double frag[NB][S + 2];                      // Phi[rowbase + s - 1][4 c + t]
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        const int col = 4 * c + t;
+#pragma unroll
+        for (int s = 0; s < S + 2; ++s) {
+            const int i = rowbase + s - 1;
+            frag[c][s] = (i >= 0 && i < N && col < r) ? a.Phi[(size_t)i * r + col] : 0.0;
+        }
+    }
+    if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;      // halos [0], [1], [NPAD+2], [NPAD+3]
+
+    for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
+        const double mu1 = a.mu1[smp], mu2 = a.mu2[smp];
+        double* hist = a.hist + (size_t)smp * (size_t)(a.nsteps + 1) * (size_t)N;
+        __syncthreads();                                       // previous sample's LDS reads are done
+        // ---- per-sample constants (compute_forcing_vector :427-461, f_gp of :556-558) and the initial state ----
+        for (int i = tid; i < NPAD; i += 256) {
+            double frPrev = 0.0, fl = 0.0, hf = 0.0, u = 0.0;
+            if (i < N) {
+                if (i > 0) {
+                    const double xl = a.x[i - 1], xr = a.x[i];
+                    const double he = a.nonuniform ? xr - xl : h;
+                    const double f1 = 0.02 * exp(mu2 * (GP_A * xl + GP_B * xr));
+                    const double f2 = 0.02 * exp(mu2 * (GP_B * xl + GP_A * xr));
+                    frPrev = (f1 * GP_B + f2 * GP_A) * (0.5 * he);
+                }
+                if (i < N - 1) {
+                    const double xl = a.x[i], xr = a.x[i + 1];
+                    const double he = a.nonuniform ? xr - xl : h;
+                    const double f1 = 0.02 * exp(mu2 * (GP_A * xl + GP_B * xr));
+                    const double f2 = 0.02 * exp(mu2 * (GP_B * xl + GP_A * xr));
+                    fl = (f1 * GP_A + f2 * GP_B) * (0.5 * he);
+                    hf = he * (f1 + f2);
+                }
+                u = a.u0[(size_t)smp * N + i];
+                hist[i] = u;
+            }
+            s_fdt[i] = a.dt * (frPrev + fl);
+            s_h[i] = hf;
+            s_u[i + 2] = u;
+        }
+        __syncthreads();
+
+        int flags = 0, info_out = 0;
+        for (int step = 0; step < a.nsteps && info_out == 0; ++step) {
+            // ---- g = M u^n + dt F (`M @ U[:, n] + At*F`, :746); rows are revisited by the same thread below ------
+            for (int i = tid; i < NPAD; i += 256) {
+                double g = 0.0;
+                if (i < N) {
+                    const double um = s_u[i + 1], u0 = s_u[i + 2], ur = s_u[i + 3];
+                    if (a.nonuniform) {
+                        double v = 0.0;
+                        if (i > 0) v = (a.x[i] - a.x[i - 1]) / 6.0 * __builtin_fma(2.0, u0, um);
+                        if (i < N - 1) v = __builtin_fma((a.x[i + 1] - a.x[i]) / 6.0, __builtin_fma(2.0, u0, ur), v);
+                        g = v + s_fdt[i];
+                    } else {
+                        double acc;
+                        if (i == 0) acc = __builtin_fma(2.0, u0, ur);
+                        else if (i == N - 1) acc = __builtin_fma(2.0, u0, um);
+                        else acc = __builtin_fma(4.0, u0, um) + ur;
+                        g = __builtin_fma(mc.h6, acc, s_fdt[i]);
+                    }
+                }
+                s_g[i] = g;
+            }
+            int k = 0;
+            bool more;
+            do {
+                // ---- assembly: A(u_k), R(u_k) per row into LDS ----------------------------------------------------
+                for (int i = tid; i < NPAD; i += 256) {
+                    double lo, di, up, R;
+                    const bool in = i < N;
+                    rom_assemble_row(i, N, s_u[i + 1], s_u[i + 2], (i + 1 < N) ? s_u[i + 3] : 0.0, in ? s_g[i] : 0.0,
+                                     (in && i > 0) ? s_h[i - 1] : 0.0, (in && i < N - 1) ? s_h[i] : 0.0, mu1, mc,
+                                     a.nonuniform, a.x, a.dt, a.E, lo, di, up, R);
+                    s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = R;
+                }
+                __syncthreads();
+                // ---- projection on the matrix cores (Galerkin in two halves: 55 instead of 110 live accumulators) --
+                if constexpr (GAL) {
+                    mfma_pass<S, NB, true, 0, NB / 2, RW>(frag, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
+                    mfma_pass<S, NB, true, NB / 2, NB, RW>(frag, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
+                } else {
+                    mfma_pass<S, NB, false, 0, NB, RW>(frag, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
+                }
+                __syncthreads();
+                // ---- reduced solve: load own columns (sum of the four waves' partials), eliminate ----------------
+                auto entry = [&](int i, int j) -> double {               // (Ar | br | wtu)[i][j], j <= RW + 1
+                    int rr = i, cc = j;
+                    if (!GAL && j < RW && (i >> 2) > (j >> 2)) { rr = j; cc = i; }   // LSPG: mirror the lower blocks
+                    return (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
+                };
+                LuRegs<NB> lu;
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    const int b = w + 4 * s;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int j = 4 * b + tt;
+                        double v = 0.0;
+                        if (b < NB && lane < RW) v = (lane >= r || j >= r) ? ((lane == j) ? 1.0 : 0.0) : entry(lane, j);
+                        lu.col[s][tt] = v;
+                    }
+                }
+                lu.rhs = (w == 3 && lane < r) ? -entry(lane, RW) : 0.0;           // solve(Ar, -br)
+                bool bad = a.force_pivoted != 0;
+                if (w == 0) lu_factor_panel(lu.col[0], 0, lane, s_m[0], bad);
+                __syncthreads();
+#pragma unroll
+                for (int p = 0; p < NB; ++p) {
+                    double m[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) m[kk] = s_m[p & 1][kk][lane];
+                    const int nxt = p + 1;
+                    if (nxt < NB && w == (nxt & 3)) {                         // look-ahead: next panel first
+                        lu_apply_block<NB>(lu.col[nxt >> 2], m, p);
+                        lu_factor_panel(lu.col[nxt >> 2], nxt, lane, s_m[nxt & 1], bad);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NSLOT; ++s) {
+                        const int b = w + 4 * s;
+                        if (b > p && b < NB && b != nxt) lu_apply_block<NB>(lu.col[s], m, p);
+                    }
+                    if (w == 3) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) lu.rhs = __builtin_fma(-m[kk], readlane_f64(lu.rhs, 4 * p + kk), lu.rhs);
+                    }
+                    if (p + 1 < NB) __syncthreads();
+                }
+                if (lane < RW) {
+#pragma unroll
+                    for (int s = 0; s < NSLOT; ++s) {
+                        const int b = w + 4 * s;
+                        if (b < NB) {
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) s_U[lane][4 * b + tt] = lu.col[s][tt];
+                        }
+                    }
+                    if (w == 3) s_U[lane][RW] = lu.rhs;
+                }
+                {
+                    const unsigned long long anybad = __ballot(bad);
+                    if (lane == 0) s_bad[w] = anybad != 0ull;
+                }
+                if (tid == 0) s_info = 0;
+                __syncthreads();
+                // ---- back substitution, every wave for itself (same values in all four) --------------------------
+                double xout = 0.0;
+                const bool fallback = (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0;      // workgroup-uniform
+                if (!fallback) {
+                    const double rd = (lane < RW) ? rcp(s_U[lane][lane]) : 0.0;
+                    double y = (lane < RW) ? s_U[lane][RW] : 0.0;
+                    double ck[RW];
+#pragma unroll
+                    for (int kc = 0; kc < RW; ++kc) ck[kc] = (lane < kc) ? s_U[lane][kc] : 0.0;
+#pragma unroll
+                    for (int kc = RW - 1; kc >= 0; --kc) {
+                        const double xk = readlane_f64(y * rd, kc);
+                        y = __builtin_fma(-ck[kc], xk, y);
+                        xout = (lane == kc) ? xk : xout;
+                    }
+                } else {
+                    // a multiplier above 1 (or a zero / non-finite pivot): partial pivoting, one wave (bg_lu_solve's routine)
+                    if (w == 0) {
+                        double row[RW + 1];
+#pragma unroll
+                        for (int j = 0; j < RW; ++j)
+                            row[j] = (lane < r && j < r) ? entry(lane, j) : ((lane == j) ? 1.0 : 0.0);
+                        row[RW] = (lane < r) ? -entry(lane, RW) : 0.0;
+                        int info;
+                        const double xs = lu_pivoted_wave<RW>(row, lane, info);
+                        if (lane < RW) s_x[lane] = xs;
+                        if (lane == 0) s_info = info;
+                    }
+                    __syncthreads();
+                    xout = (lane < RW) ? s_x[lane] : 0.0;
+                    if (s_info != 0 && info_out == 0) info_out = s_info;
+                }
+                // ---- q = Phi^T u_k + dq, err = |dq| / |q|  (:770-776) ---------------------------------------------
+                double wtu = 0.0;
+                if (lane < r) {
+                    if constexpr (GAL) wtu = entry(lane, RW + 1);
+                    else wtu = (s_wtu[0][lane] + s_wtu[1][lane]) + (s_wtu[2][lane] + s_wtu[3][lane]);
+                }
+                const double dq = (lane < r) ? xout : 0.0;
+                const double qn = (lane < r) ? wtu + dq : 0.0;
+                double nd, nq;
+                wave_sum2(dq * dq, qn * qn, nd, nq);
+                nd = sqrt(nd); nq = sqrt(nq);
+                const double err = nd / nq;
+                ++k;
+                more = (err > a.tol) && (k < a.max_it) && info_out == 0;
+                if (!(err - err == 0.0)) flags |= BG_FLAG_NONFINITE;
+                if (k >= a.max_it) flags |= BG_FLAG_HIT_CAP;
+                if (w == 0 && lane < RW) s_q[lane] = qn;
+                __syncthreads();
+                // ---- lift u_{k+1} = Phi q from the register-resident basis (:773) --------------------------------
+                {
+                    double qv[NB];
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) qv[c] = s_q[4 * c + t];          // zero beyond r
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        double p = 0.0;
+#pragma unroll
+                        for (int c = 0; c < NB; ++c) p = __builtin_fma(frag[c][s + 1], qv[c], p);
+                        p += dpp_mov<0xB1>(p);             // quad_perm [1,0,3,2]: sum over the four t lanes
+                        p += dpp_mov<0x4E>(p);             // quad_perm [2,3,0,1]
+                        if (t == 0) {
+                            const int i = rowbase + s;
+                            s_u[i + 2] = (i < N) ? p : 0.0;
+                        }
+                    }
+                }
+                __syncthreads();
+            } while (more);
+            // ---- U[:, n+1] = U1 (:779): one coalesced row ----------------------------------------------------------
+            double* hrow = hist + (size_t)(step + 1) * N;
+            for (int i = tid; i < N; i += 256) hrow[i] = s_u[i + 2];
+            if (tid == 0) a.iters[(size_t)smp * a.nsteps + step] = k;
+        }
+        if (tid == 0) {
+            a.flags[smp] = flags;
+            if (a.info) a.info[smp] = info_out;
+        }
+    }
+}
+
+template <int S, int NB>
+void launch_fused(int projection, int grid, hipStream_t st, const RomRunArgs& a)
+{
+    if (projection == BG_PROJ_GALERKIN)
+        hipLaunchKernelGGL((rom_fused_kernel<S, NB, BG_PROJ_GALERKIN>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((rom_fused_kernel<S, NB, BG_PROJ_LSPG>), dim3(grid), dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bg_rom_run_max_r(void) { return 40; }
+
+int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double* x, const double* Phi, const double* u0,
+               const double* mu1, const double* mu2, double dt, double E, double tol, int max_it, int options,
+               double* hist, int32_t* iters, int32_t* flags, int32_t* info, void* stream)
+{
+    if (N < 2 || B < 0 || r < 1 || nsteps < 0 || max_it < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
+    if (projection != BG_PROJ_GALERKIN && projection != BG_PROJ_LSPG) return BG_ERR_PROJECTION;
+    if (N > 512) return BG_ERR_UNSUPPORTED_N;
+    if (r > 40) return BG_ERR_UNSUPPORTED_R;
+    if (B == 0) return BG_OK;
+    if (!x || !Phi || !u0 || !mu1 || !mu2 || !hist || !flags || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
+    RomRunArgs a;
+    a.x = x; a.Phi = Phi; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
+    a.info = info; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.B = B; a.r = r; a.nsteps = nsteps; a.max_it = max_it;
+    a.supg = options & BG_OPT_SUPG; a.nonuniform = (options & BG_OPT_NONUNIFORM) ? 1 : 0;
+    a.force_pivoted = (options & BG_OPT_FORCE_PIVOTED) ? 1 : 0;
+    const int cus = device_cu_count();
+    const int grid = B < cus ? B : cus;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = r <= 8 ? 2 : (r <= 24 ? 6 : 10);
+    const int s4 = N <= 256 ? 4 : 8;
+    switch (s4 * 100 + nb) {
+        case 402: launch_fused<4, 2>(projection, grid, st, a); break;
+        case 406: launch_fused<4, 6>(projection, grid, st, a); break;
+        case 410: launch_fused<4, 10>(projection, grid, st, a); break;
+        case 802: launch_fused<8, 2>(projection, grid, st, a); break;
+        case 806: launch_fused<8, 6>(projection, grid, st, a); break;
+        case 810: launch_fused<8, 10>(projection, grid, st, a); break;
+        default: return BG_ERR_UNSUPPORTED_R;
+    }
+    return check_launch();
+}
+
+}  // extern "C"

@@ -46,7 +46,8 @@ enum { BG_PROJ_GALERKIN = 0, BG_PROJ_LSPG = 1 };
 enum { BG_OPT_SUPG = 1,        /* include the SUPG vector (fom_burgers, pod_prom_burgers, pod_ann_prom) */
        BG_OPT_NONUNIFORM = 2,  /* x is not a linspace: use the per-element-length kernels          */
        BG_OPT_W_COLMAJOR = 4,  /* bg_rom_reduce*: W is [r][N] (per sample), not [N][r]             */
-       BG_OPT_MFMA_16X16 = 8   /* bg_rom_reduce*: use the v_mfma_f64_16x16x4 kernel for every r (A/B timing, tests) */ };
+       BG_OPT_MFMA_16X16 = 8,  /* bg_rom_reduce*: use the v_mfma_f64_16x16x4 kernel for every r (A/B timing, tests) */
+       BG_OPT_FORCE_PIVOTED = 16 /* bg_rom_run: take the partial-pivoting branch of the reduced solve every time (tests) */ };
 
 /* per-sample status bits written to `flags` */
 enum { BG_FLAG_HIT_CAP = 1, BG_FLAG_NONFINITE = 2 };
@@ -197,6 +198,27 @@ int bg_rom_lift(int N, int B, int r, const double *x, const double *Phi, const d
 int bg_lu_solve_update(int n, int B, const double *A, const double *rhs, int mode, const double *wtu,
                        double *q, double *dq, double tol, int max_it, int32_t *active, int32_t *iters,
                        int32_t *flags, int32_t *counter, int32_t *info, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * bg_rom_run -- batched replacement of FEMBurgers.pod_prom_burgers, the WHOLE time loop on the device
+ *   reference: FEM/fem_burgers.py:709-785.  One workgroup owns one sample for all time steps and Picard iterations:
+ *   assembly, fp64-MFMA projection (as bg_rom_reduce), the r x r solve, q = Phi^T u + dq, the stopping test
+ *   err = |dq|/|q| > tol and k < max_it (:729, :776) and the lift u = Phi q run with no kernel boundary and no host
+ *   in between; HBM sees u0 once and one N-row history write per time step.
+ *   Phi    [N][r] row-major (the reference's U_modes .npy layout), shared by all samples; N <= 512, r <= 40
+ *          (bg_rom_run_max_r) -- beyond that use bg_rom_reduce + bg_lu_solve_update (BG_ERR_UNSUPPORTED_R / _N)
+ *   u0, mu1, mu2, hist, iters, flags: as bg_fom_run (hist[b][0] = u0[b]; flags BG_FLAG_*)
+ *   info   [B] or NULL: 0, or k+1 when the reduced matrix of a sample is exactly singular at elimination step k
+ *          (np.linalg.solve raises LinAlgError there); that sample stops and its remaining history is undefined
+ *   options BG_OPT_SUPG (pod_prom_burgers has it) | BG_OPT_NONUNIFORM | BG_OPT_FORCE_PIVOTED
+ *   The reduced solve is np.linalg.solve's partial-pivoting LU: as long as every multiplier stays <= 1 in modulus the
+ *   pivot is the diagonal and no search is made; otherwise the system is redone with the pivot search of bg_lu_solve.
+ * --------------------------------------------------------------------------------- */
+int bg_rom_run_max_r(void);
+int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double *x, const double *Phi,
+               const double *u0, const double *mu1, const double *mu2, double dt, double E, double tol,
+               int max_it, int options, double *hist, int32_t *iters, int32_t *flags, int32_t *info,
+               void *stream);
 
 /* =================================================================================
  * bg_fd_run -- batched replacement of FDBurgers.fom_burgers_newton (analytical Jacobian)
