@@ -16,7 +16,9 @@
 // b = w, w+4, w+8 (the right-hand side rides with wave 3); the owner of panel p factors it in its own registers
 // (no communication inside a panel), publishes the four multiplier vectors through LDS, and every wave applies them
 // to its own columns with v_readlane broadcasts of the pivot rows.  The owner of panel p+1 updates that block first
-// and factors it while the others are still applying panel p (look-ahead): one barrier per panel.
+// and factors it while the others are still applying panel p (look-ahead): one barrier per panel.  Every update is an
+// FMA over all 64 lanes, so the multipliers are formed for the rows ABOVE the pivot too (Gauss-Jordan) at no extra
+// instruction: the elimination ends with a diagonal system and the 40 dependent steps of a back substitution vanish.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,9 +26,19 @@
 #include "abi_common.hpp"
 #include "rom_device.hpp"
 
+// Phase ablation for tools/time_fused.py (never defined in the product build): BG_FUSED_ABLATE is a bit mask of phases to
+// compile out (1 MFMA passes, 2 elimination, 4 back substitution, 8 lift, 16 assembly); the iteration count is then
+// fixed at 5 per time step and the pivoted fallback is disabled, so that the garbage values cannot change the control flow.
+#ifndef BG_FUSED_ABLATE
+#define BG_FUSED_ABLATE -1
+#endif
+
 namespace {
 
 using namespace bg;
+constexpr int kAblate = BG_FUSED_ABLATE;
+constexpr bool kTiming = kAblate >= 0;
+constexpr bool skip(int bit) { return kTiming && (kAblate & bit) != 0; }
 
 struct RomRunArgs {
     const double* x;        // [N]
@@ -44,76 +56,115 @@ struct RomRunArgs {
 
 // ---- one MFMA pass over this wave's rows: pairs (ca, cb) with ca in [CA0, CA1) ---------------------------------
 // Same operand layout, accumulation order and block-partial summation as rom_reduce4_kernel (rom.hip), so the
-// reduced system has the bits of the batched path.
-template <int S, int NB, bool GAL, int CA0, int CA1, int RW>
-__device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S + 2], const double (*__restrict__ s_coef)[4],
-                                          const double* __restrict__ s_u, int rowbase, int t, int w, int lane,
+// reduced system has the bits of the batched path.  frag[c][s] = Phi[rowbase + s][4 c + t]; the two halo rows
+// Phi[rowbase - 1], Phi[rowbase + S] of every column block sit in LDS (s_halo[0 / 1][c][tid], one private slot per
+// thread: conflict-free 8-byte reads) and are fetched when the first / last row step needs them -- 40 VGPRs fewer
+// live across the whole kernel.  LAST: this pass also carries the Phi^T u accumulators of the LSPG form.
+template <int S, int NB, bool GAL, int CA0, int CA1, bool LAST, int RW>
+__device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const double (*__restrict__ s_halo)[NB][256],
+                                          const double (*__restrict__ s_coef)[4], const double* __restrict__ s_u,
+                                          int rowbase, int t, int w, int lane, int tid,
                                           double (*__restrict__ s_red)[RW][RW + 4], double (*__restrict__ s_wtu)[RW])
 {
-    constexpr int NACC = GAL ? (CA1 - CA0) * (NB + 1) : NB * (NB + 1) / 2 + NB + NB;
+    constexpr int NROW = GAL ? (CA1 - CA0) * (NB + 1) : (CA1 - CA0) * (2 * NB - CA0 - CA1 + 1) / 2 + (CA1 - CA0);
+    constexpr int NACC = NROW + ((!GAL && LAST) ? NB : 0);
     double acc[NACC];
 #pragma unroll
     for (int p = 0; p < NACC; ++p) acc[p] = 0.0;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
+    // B operands of row step s: Y = (A Phi) rows, X = extra block [R, u, 0, 0]
+    auto operands = [&](int s, double (&Y)[NB], double& X) {
         const int i = rowbase + s;
         const double lo = s_coef[i][0], di = s_coef[i][1], up = s_coef[i][2], R = s_coef[i][3];
         const double ui = s_u[i + 2];
-        double Y[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
-            double y = lo * frag[c][s];
-            y = __builtin_fma(di, frag[c][s + 1], y);
-            y = __builtin_fma(up, frag[c][s + 2], y);
+            const double below = (s == 0) ? s_halo[0][c][tid] : frag[c][s == 0 ? 0 : s - 1];
+            const double above = (s == S - 1) ? s_halo[1][c][tid] : frag[c][s == S - 1 ? s : s + 1];
+            double y = lo * below;
+            y = __builtin_fma(di, frag[c][s], y);
+            y = __builtin_fma(up, above, y);
             Y[c] = y;
         }
-        const double X = (t == 0) ? R : ((t == 1) ? ui : 0.0);      // extra B block [R, u, 0, 0]
+        X = (t == 0) ? R : ((t == 1) ? ui : 0.0);
+    };
+    // Software pipeline: the operands of step s + 1 are formed (LDS reads + 3 NB VALU ops) between the MFMAs of step s,
+    // which leave the vector ALU idle for 12 of their 16 cycles; without it the two phases alternate (27 cycles per MFMA).
+    double Y[NB], X;
+    operands(0, Y, X);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        double Yn[NB], Xn = 0.0;
+        if (s + 1 < S) operands(s + 1, Yn, Xn);
         int p = 0;
         if constexpr (GAL) {
 #pragma unroll
             for (int ca = CA0; ca < CA1; ++ca) {
 #pragma unroll
                 for (int cb = 0; cb < NB; ++cb, ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s + 1], Y[cb], acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s + 1], X, acc[p], 0, 0, 0);
+                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], Y[cb], acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], X, acc[p], 0, 0, 0);
                 ++p;
             }
         } else {
 #pragma unroll
-            for (int ca = 0; ca < NB; ++ca) {
+            for (int ca = CA0; ca < CA1; ++ca) {
 #pragma unroll
                 for (int cb = ca; cb < NB; ++cb, ++p)
                     acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(Y[ca], Y[cb], acc[p], 0, 0, 0);
                 acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(Y[ca], X, acc[p], 0, 0, 0);
                 ++p;
             }
+            if constexpr (LAST) {
 #pragma unroll
-            for (int ca = 0; ca < NB; ++ca, ++p)
-                acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s + 1], X, acc[p], 0, 0, 0);
+                for (int ca = 0; ca < NB; ++ca, ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], X, acc[p], 0, 0, 0);
+            }
         }
+        if (s + 1 < S) {
+            // issue order of this step: the next step's LDS reads, a few MFMAs to cover their latency, then MFMA / VALU pairs
+            if (s + 1 == S - 1) __builtin_amdgcn_sched_group_barrier(0x100, 3 + NB, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#pragma unroll
+            for (int q = 0; q < 3 * NB + 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c) Y[c] = Yn[c];
+            X = Xn;
+        }
+        __builtin_amdgcn_sched_barrier(0);       // nothing moves across a step: bounded register pressure
     }
     // sum the four block partials of every pair (lanes differing in bits 2..3), park them per wave in LDS
     const int oi = lane >> 4, oj = lane & 3;
     const bool writer = ((lane >> 2) & 3) == 3;
-    const int wslot = writer ? w : 4;            // idle lanes store into the dump slab: no branches
     int p = 0;
+    if constexpr (skip(32)) {                    // timing only: keep the MFMAs alive, drop the block sums and stores
+        double v = 0.0;
 #pragma unroll
-    for (int ca = (GAL ? CA0 : 0); ca < (GAL ? CA1 : NB); ++ca) {
+        for (int q = 0; q < NACC; ++q) v += acc[q];
+        if (writer) s_red[w][oi][oj] = v;
+        return;
+    }
+#pragma unroll
+    for (int ca = CA0; ca < CA1; ++ca) {
 #pragma unroll
         for (int cb = (GAL ? 0 : ca); cb <= NB; ++cb, ++p) {
             double v = acc[p];
             v += dpp_mov<0x114>(v);          // row_shr:4
             v += dpp_mov<0x118>(v);          // row_shr:8 -> lanes with blk == 3 hold the sum
-            s_red[wslot][4 * ca + oi][4 * cb + oj] = v;
+            if (writer) s_red[w][4 * ca + oi][4 * cb + oj] = v;
         }
     }
-    if constexpr (!GAL) {
+    if constexpr (!GAL && LAST) {
 #pragma unroll
         for (int ca = 0; ca < NB; ++ca, ++p) {
             double v = acc[p];
             v += dpp_mov<0x114>(v);
             v += dpp_mov<0x118>(v);
-            s_wtu[(writer && oj == 1) ? w : 4][4 * ca + oi] = v;
+            if (writer && oj == 1) s_wtu[w][4 * ca + oi] = v;
         }
     }
 }
@@ -136,22 +187,48 @@ __device__ __forceinline__ void lu_apply_block(double (&c)[4], const double (&m)
 }
 
 // factor the panel held in c[0..3] (columns 4p .. 4p+3, pivots in lanes 4p .. 4p+3); multipliers -> sm[kk][lane]
-__device__ __forceinline__ void lu_factor_panel(double (&c)[4], int p, int lane, double (*__restrict__ sm)[64], bool& bad)
+// gmax: running maximum of the sub-diagonal |multipliers| (the partial-pivoting guard); zero_piv: a pivot was exactly 0
+__device__ __forceinline__ void lu_factor_panel(double (&c)[4], int p, int lane, double (*__restrict__ sm)[64], double& gmax,
+                                                bool& zero_piv)
 {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const int k = 4 * p + kk;
         const double piv = readlane_f64(c[kk], k);
         const double rp = rcp(piv);
-        const double m = (lane > k) ? c[kk] * rp : 0.0;
-        bad = bad || !(fabs(m) <= 1.0) || !(piv - piv == 0.0) || piv == 0.0;
+        const double m = (lane != k) ? c[kk] * rp : 0.0;          // rows ABOVE the pivot too (Gauss-Jordan, see the kernel)
+        gmax = fmax(gmax, (lane > k) ? fabs(m) : 0.0);            // branch-free: a short-circuit here costs 3.7 us per solve
+        zero_piv = zero_piv | (piv == 0.0);
 #pragma unroll
         for (int jj = kk + 1; jj < 4; ++jj) c[jj] = __builtin_fma(-m, readlane_f64(c[jj], k), c[jj]);
         sm[kk][lane] = m;
     }
 }
 
-template <int S, int NB, int PROJ>
+// The partial-pivoting solve of the repair kernel (PIV): one wave reloads the summed system from the per-wave partials and
+// runs the routine of bg_lu_solve.  It lives in a kernel of its own: as a cold branch (even out of line) inside the fast
+// kernel it cost 4.7 us per iteration through the register allocation around the call site.
+template <int NB, bool GAL>
+__device__ __forceinline__ void pivoted_solve(const double (*__restrict__ s_red)[4 * NB][4 * NB + 4],
+                                              double* __restrict__ s_x, int* __restrict__ s_info, int lane, int r)
+{
+    constexpr int RW = 4 * NB;
+    auto entry = [&](int i, int j) -> double {
+        int rr = i, cc = j;
+        if (!GAL && j < RW && (i >> 2) > (j >> 2)) { rr = j; cc = i; }
+        return (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
+    };
+    double row[RW + 1];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) row[j] = (lane < r && j < r) ? entry(lane, j) : ((lane == j) ? 1.0 : 0.0);
+    row[RW] = (lane < r) ? -entry(lane, RW) : 0.0;
+    int info;
+    const double xs = lu_pivoted_wave<RW>(row, lane, info);
+    if (lane < RW) s_x[lane] = xs;
+    if (lane == 0) *s_info = info;
+}
+
+template <int S, int NB, int PROJ, bool PIV>
 __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
 {
     constexpr int NPAD = 64 * S;
@@ -163,10 +240,11 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
     __shared__ double s_h[NPAD];                 // hfs: h_e (f(gp1) + f(gp2)) per element
     __shared__ double s_fdt[NPAD];               // dt F
     __shared__ double s_coef[NPAD][4];
-    __shared__ double s_red[5][RW][RW + 4];      // per-wave  Ar | [br, W^T u (Galerkin), 0, 0]; [4] = dump for idle lanes
-    __shared__ double s_wtu[5][RW];              // per-wave  W^T u (LSPG); [4] = dump
+    __shared__ double s_red[4][RW][RW + 4];      // per-wave  Ar | [br, W^T u (Galerkin), 0, 0]
+    __shared__ double s_wtu[4][RW];              // per-wave  W^T u (LSPG)
+    __shared__ double s_halo[2][NB][256];        // Phi rows just below / above every thread's S rows, per column block
     __shared__ double s_m[2][4][64];             // multipliers of the current / next panel
-    __shared__ double s_U[RW][RW + 1];           // eliminated system: U | y
+    __shared__ double s_diag[RW], s_y[RW];       // what the elimination leaves: diagonal and right-hand side
     __shared__ double s_q[RW];
     __shared__ double s_x[RW];                   // solution of the pivoted fallback
     __shared__ int s_bad[4];
@@ -176,23 +254,26 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
     const int t = lane & 3, owner = 16 * w + (lane >> 2);
     const int N = a.N, r = a.r;
     const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
-    const MeshConst mc = make_mesh_const(h, a.dt, a.E, a.supg);
     const int rowbase = owner * S;
 
     // ---- basis fragments: loaded once per workgroup, kept in registers for every sample ------------------------
-    double frag[NB][S + 2];                      // Phi[rowbase + s - 1][4 c + t]
+    double frag[NB][S];                          // Phi[rowbase + s][4 c + t]
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
         const int col = 4 * c + t;
 #pragma unroll
-        for (int s = 0; s < S + 2; ++s) {
-            const int i = rowbase + s - 1;
-            frag[c][s] = (i >= 0 && i < N && col < r) ? a.Phi[(size_t)i * r + col] : 0.0;
+        for (int s = 0; s < S; ++s) {
+            const int i = rowbase + s;
+            frag[c][s] = (i < N && col < r) ? a.Phi[(size_t)i * r + col] : 0.0;
         }
+        const int il = rowbase - 1, ih = rowbase + S;
+        s_halo[0][c][tid] = (il >= 0 && il < N && col < r) ? a.Phi[(size_t)il * r + col] : 0.0;
+        s_halo[1][c][tid] = (ih < N && col < r) ? a.Phi[(size_t)ih * r + col] : 0.0;
     }
     if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;      // halos [0], [1], [NPAD+2], [NPAD+3]
 
     for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
+        if (PIV && !a.force_pivoted && a.info[smp] != BG_INFO_NEEDS_PIVOTING) continue;      // workgroup-uniform
         const double mu1 = a.mu1[smp], mu2 = a.mu2[smp];
         double* hist = a.hist + (size_t)smp * (size_t)(a.nsteps + 1) * (size_t)N;
         __syncthreads();                                       // previous sample's LDS reads are done
@@ -225,7 +306,8 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
         __syncthreads();
 
         int flags = 0, info_out = 0;
-        for (int step = 0; step < a.nsteps && info_out == 0; ++step) {
+        bool aborted = false;                    // fast kernel: the multiplier guard tripped, the repair kernel redoes this sample
+        for (int step = 0; step < a.nsteps && info_out == 0 && !aborted; ++step) {
             // ---- g = M u^n + dt F (`M @ U[:, n] + At*F`, :746); rows are revisited by the same thread below ------
             for (int i = tid; i < NPAD; i += 256) {
                 double g = 0.0;
@@ -241,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                         if (i == 0) acc = __builtin_fma(2.0, u0, ur);
                         else if (i == N - 1) acc = __builtin_fma(2.0, u0, um);
                         else acc = __builtin_fma(4.0, u0, um) + ur;
-                        g = __builtin_fma(mc.h6, acc, s_fdt[i]);
+                        g = __builtin_fma(h / 6.0, acc, s_fdt[i]);
                     }
                 }
                 s_g[i] = g;
@@ -250,9 +332,11 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
             bool more;
             do {
                 // ---- assembly: A(u_k), R(u_k) per row into LDS ----------------------------------------------------
+                if (!skip(16))
                 for (int i = tid; i < NPAD; i += 256) {
                     double lo, di, up, R;
                     const bool in = i < N;
+                    const MeshConst mc = make_mesh_const(h, a.dt, a.E, a.supg);   // wave-uniform; rebuilt here rather than held in 14 VGPRs
                     rom_assemble_row(i, N, s_u[i + 1], s_u[i + 2], (i + 1 < N) ? s_u[i + 3] : 0.0, in ? s_g[i] : 0.0,
                                      (in && i > 0) ? s_h[i - 1] : 0.0, (in && i < N - 1) ? s_h[i] : 0.0, mu1, mc,
                                      a.nonuniform, a.x, a.dt, a.E, lo, di, up, R);
@@ -260,11 +344,11 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                 }
                 __syncthreads();
                 // ---- projection on the matrix cores (Galerkin in two halves: 55 instead of 110 live accumulators) --
-                if constexpr (GAL) {
-                    mfma_pass<S, NB, true, 0, NB / 2, RW>(frag, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
-                    mfma_pass<S, NB, true, NB / 2, NB, RW>(frag, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
-                } else {
-                    mfma_pass<S, NB, false, 0, NB, RW>(frag, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
+                // two passes over the rows, each with half of the accumulators live (Galerkin 55 + 55, LSPG 45 + 30 at r = 40)
+                constexpr int CM = GAL ? NB / 2 : (NB + 1) / 3;
+                if constexpr (!skip(1)) {
+                    mfma_pass<S, NB, GAL, 0, CM, false, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
+                    mfma_pass<S, NB, GAL, CM, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
                 }
                 __syncthreads();
                 // ---- reduced solve: load own columns (sum of the four waves' partials), eliminate ----------------
@@ -273,91 +357,71 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                     if (!GAL && j < RW && (i >> 2) > (j >> 2)) { rr = j; cc = i; }   // LSPG: mirror the lower blocks
                     return (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
                 };
-                LuRegs<NB> lu;
-#pragma unroll
-                for (int s = 0; s < NSLOT; ++s) {
-                    const int b = w + 4 * s;
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const int j = 4 * b + tt;
-                        double v = 0.0;
-                        if (b < NB && lane < RW) v = (lane >= r || j >= r) ? ((lane == j) ? 1.0 : 0.0) : entry(lane, j);
-                        lu.col[s][tt] = v;
-                    }
-                }
-                lu.rhs = (w == 3 && lane < r) ? -entry(lane, RW) : 0.0;           // solve(Ar, -br)
-                bool bad = a.force_pivoted != 0;
-                if (w == 0) lu_factor_panel(lu.col[0], 0, lane, s_m[0], bad);
-                __syncthreads();
-#pragma unroll
-                for (int p = 0; p < NB; ++p) {
-                    double m[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) m[kk] = s_m[p & 1][kk][lane];
-                    const int nxt = p + 1;
-                    if (nxt < NB && w == (nxt & 3)) {                         // look-ahead: next panel first
-                        lu_apply_block<NB>(lu.col[nxt >> 2], m, p);
-                        lu_factor_panel(lu.col[nxt >> 2], nxt, lane, s_m[nxt & 1], bad);
-                    }
-#pragma unroll
-                    for (int s = 0; s < NSLOT; ++s) {
-                        const int b = w + 4 * s;
-                        if (b > p && b < NB && b != nxt) lu_apply_block<NB>(lu.col[s], m, p);
-                    }
-                    if (w == 3) {
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) lu.rhs = __builtin_fma(-m[kk], readlane_f64(lu.rhs, 4 * p + kk), lu.rhs);
-                    }
-                    if (p + 1 < NB) __syncthreads();
-                }
-                if (lane < RW) {
-#pragma unroll
-                    for (int s = 0; s < NSLOT; ++s) {
-                        const int b = w + 4 * s;
-                        if (b < NB) {
-#pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) s_U[lane][4 * b + tt] = lu.col[s][tt];
-                        }
-                    }
-                    if (w == 3) s_U[lane][RW] = lu.rhs;
-                }
-                {
-                    const unsigned long long anybad = __ballot(bad);
-                    if (lane == 0) s_bad[w] = anybad != 0ull;
-                }
-                if (tid == 0) s_info = 0;
-                __syncthreads();
-                // ---- back substitution, every wave for itself (same values in all four) --------------------------
                 double xout = 0.0;
-                const bool fallback = (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0;      // workgroup-uniform
-                if (!fallback) {
-                    const double rd = (lane < RW) ? rcp(s_U[lane][lane]) : 0.0;
-                    double y = (lane < RW) ? s_U[lane][RW] : 0.0;
-                    double ck[RW];
-#pragma unroll
-                    for (int kc = 0; kc < RW; ++kc) ck[kc] = (lane < kc) ? s_U[lane][kc] : 0.0;
-#pragma unroll
-                    for (int kc = RW - 1; kc >= 0; --kc) {
-                        const double xk = readlane_f64(y * rd, kc);
-                        y = __builtin_fma(-ck[kc], xk, y);
-                        xout = (lane == kc) ? xk : xout;
-                    }
-                } else {
-                    // a multiplier above 1 (or a zero / non-finite pivot): partial pivoting, one wave (bg_lu_solve's routine)
-                    if (w == 0) {
-                        double row[RW + 1];
-#pragma unroll
-                        for (int j = 0; j < RW; ++j)
-                            row[j] = (lane < r && j < r) ? entry(lane, j) : ((lane == j) ? 1.0 : 0.0);
-                        row[RW] = (lane < r) ? -entry(lane, RW) : 0.0;
-                        int info;
-                        const double xs = lu_pivoted_wave<RW>(row, lane, info);
-                        if (lane < RW) s_x[lane] = xs;
-                        if (lane == 0) s_info = info;
-                    }
+                if constexpr (PIV) {
+                    if (tid == 0) s_info = 0;
+                    __syncthreads();
+                    if (w == 0) pivoted_solve<NB, GAL>(s_red, s_x, &s_info, lane, r);
                     __syncthreads();
                     xout = (lane < RW) ? s_x[lane] : 0.0;
                     if (s_info != 0 && info_out == 0) info_out = s_info;
+                } else {
+                    LuRegs<NB> lu;
+#pragma unroll
+                    for (int s = 0; s < NSLOT; ++s) {
+                        const int b = w + 4 * s;
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const int j = 4 * b + tt;
+                            double v = 0.0;
+                            if (b < NB && lane < RW) v = (lane >= r || j >= r) ? ((lane == j) ? 1.0 : 0.0) : entry(lane, j);
+                            lu.col[s][tt] = v;
+                        }
+                    }
+                    lu.rhs = (w == 3 && lane < r) ? -entry(lane, RW) : 0.0;           // solve(Ar, -br)
+                    double gmax = 0.0;
+                    bool zero_piv = false;
+                    if (w == 0) lu_factor_panel(lu.col[0], 0, lane, s_m[0], gmax, zero_piv);
+                    __syncthreads();
+#pragma unroll
+                    for (int p = 0; p < (skip(2) ? 0 : NB); ++p) {
+                        double m[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) m[kk] = s_m[p & 1][kk][lane];
+                        const int nxt = p + 1;
+                        if (nxt < NB && w == (nxt & 3)) {                         // look-ahead: next panel first
+                            lu_apply_block<NB>(lu.col[nxt >> 2], m, p);
+                            lu_factor_panel(lu.col[nxt >> 2], nxt, lane, s_m[nxt & 1], gmax, zero_piv);
+                        }
+#pragma unroll
+                        for (int s = 0; s < NSLOT; ++s) {
+                            const int b = w + 4 * s;
+                            if (b > p && b < NB && b != nxt) lu_apply_block<NB>(lu.col[s], m, p);
+                        }
+                        if (w == 3) {
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) lu.rhs = __builtin_fma(-m[kk], readlane_f64(lu.rhs, 4 * p + kk), lu.rhs);
+                        }
+                        if (p + 1 < NB) __syncthreads();
+                    }
+                    // The multipliers cover the rows above the pivot as well (the FMAs run on all 64 lanes anyway), so what is
+                    // left is diagonal: x_k = y_k / d_k, no back substitution.  Publish d (owner of each column) and y (wave 3).
+#pragma unroll
+                    for (int s = 0; s < NSLOT; ++s) {
+                        const int b = w + 4 * s;
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt)
+                            if (b < NB && lane == 4 * b + tt) s_diag[lane] = lu.col[s][tt];
+                    }
+                    if (w == 3 && lane < RW) s_y[lane] = lu.rhs;
+                    {
+                        const unsigned long long anybad = __ballot(zero_piv | !(gmax <= 1.0));
+                        if (lane == 0) s_bad[w] = anybad != 0ull;
+                    }
+                    // ---- solution, every wave for itself (same values in all four) ---------------------------------------
+                    __syncthreads();
+                    if (!kTiming && (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0) aborted = true;      // workgroup-uniform
+                    xout = (lane < RW) ? s_y[lane] * rcp(s_diag[lane]) : 0.0;
                 }
                 // ---- q = Phi^T u_k + dq, err = |dq| / |q|  (:770-776) ---------------------------------------------
                 double wtu = 0.0;
@@ -372,13 +436,14 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                 nd = sqrt(nd); nq = sqrt(nq);
                 const double err = nd / nq;
                 ++k;
-                more = (err > a.tol) && (k < a.max_it) && info_out == 0;
+                more = (err > a.tol) && (k < a.max_it) && info_out == 0 && !aborted;
+                if (kTiming) more = k < 5;
                 if (!(err - err == 0.0)) flags |= BG_FLAG_NONFINITE;
                 if (k >= a.max_it) flags |= BG_FLAG_HIT_CAP;
                 if (w == 0 && lane < RW) s_q[lane] = qn;
                 __syncthreads();
                 // ---- lift u_{k+1} = Phi q from the register-resident basis (:773) --------------------------------
-                {
+                if (!skip(8)) {
                     double qv[NB];
 #pragma unroll
                     for (int c = 0; c < NB; ++c) qv[c] = s_q[4 * c + t];          // zero beyond r
@@ -386,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                     for (int s = 0; s < S; ++s) {
                         double p = 0.0;
 #pragma unroll
-                        for (int c = 0; c < NB; ++c) p = __builtin_fma(frag[c][s + 1], qv[c], p);
+                        for (int c = 0; c < NB; ++c) p = __builtin_fma(frag[c][s], qv[c], p);
                         p += dpp_mov<0xB1>(p);             // quad_perm [1,0,3,2]: sum over the four t lanes
                         p += dpp_mov<0x4E>(p);             // quad_perm [2,3,0,1]
                         if (t == 0) {
@@ -404,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
         }
         if (tid == 0) {
             a.flags[smp] = flags;
-            if (a.info) a.info[smp] = info_out;
+            a.info[smp] = aborted ? BG_INFO_NEEDS_PIVOTING : info_out;
         }
     }
 }
@@ -413,9 +478,19 @@ template <int S, int NB>
 void launch_fused(int projection, int grid, hipStream_t st, const RomRunArgs& a)
 {
     if (projection == BG_PROJ_GALERKIN)
-        hipLaunchKernelGGL((rom_fused_kernel<S, NB, BG_PROJ_GALERKIN>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((rom_fused_kernel<S, NB, BG_PROJ_GALERKIN, false>), dim3(grid), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((rom_fused_kernel<S, NB, BG_PROJ_LSPG>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((rom_fused_kernel<S, NB, BG_PROJ_LSPG, false>), dim3(grid), dim3(256), 0, st, a);
+}
+
+// The repair kernel: samples the fast kernel gave up on (info = BG_INFO_NEEDS_PIVOTING), redone from u0 with the
+// partial-pivoting solve.  One shape covers every N <= 512 and r <= 40 (zero padding); it is not a hot path.
+void launch_repair(int projection, int grid, hipStream_t st, const RomRunArgs& a)
+{
+    if (projection == BG_PROJ_GALERKIN)
+        hipLaunchKernelGGL((rom_fused_kernel<8, 10, BG_PROJ_GALERKIN, true>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((rom_fused_kernel<8, 10, BG_PROJ_LSPG, true>), dim3(grid), dim3(256), 0, st, a);
 }
 
 }  // namespace
@@ -433,7 +508,7 @@ int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double* x,
     if (N > 512) return BG_ERR_UNSUPPORTED_N;
     if (r > 40) return BG_ERR_UNSUPPORTED_R;
     if (B == 0) return BG_OK;
-    if (!x || !Phi || !u0 || !mu1 || !mu2 || !hist || !flags || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
+    if (!x || !Phi || !u0 || !mu1 || !mu2 || !hist || !flags || !info || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
     RomRunArgs a;
     a.x = x; a.Phi = Phi; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
     a.info = info; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.B = B; a.r = r; a.nsteps = nsteps; a.max_it = max_it;
@@ -444,15 +519,22 @@ int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double* x,
     hipStream_t st = (hipStream_t)stream;
     const int nb = r <= 8 ? 2 : (r <= 24 ? 6 : 10);
     const int s4 = N <= 256 ? 4 : 8;
-    switch (s4 * 100 + nb) {
-        case 402: launch_fused<4, 2>(projection, grid, st, a); break;
-        case 406: launch_fused<4, 6>(projection, grid, st, a); break;
-        case 410: launch_fused<4, 10>(projection, grid, st, a); break;
-        case 802: launch_fused<8, 2>(projection, grid, st, a); break;
-        case 806: launch_fused<8, 6>(projection, grid, st, a); break;
-        case 810: launch_fused<8, 10>(projection, grid, st, a); break;
-        default: return BG_ERR_UNSUPPORTED_R;
+    if (!a.force_pivoted) {
+        switch (s4 * 100 + nb) {
+#ifndef BG_FUSED_ONLY_810                 // (experiments compile the headline instantiation alone)
+            case 402: launch_fused<4, 2>(projection, grid, st, a); break;
+            case 406: launch_fused<4, 6>(projection, grid, st, a); break;
+            case 410: launch_fused<4, 10>(projection, grid, st, a); break;
+            case 802: launch_fused<8, 2>(projection, grid, st, a); break;
+            case 806: launch_fused<8, 6>(projection, grid, st, a); break;
+#endif
+            case 810: launch_fused<8, 10>(projection, grid, st, a); break;
+            default: return BG_ERR_UNSUPPORTED_R;
+        }
+        const int rc = check_launch();
+        if (rc != BG_OK) return rc;
     }
+    if (kAblate < 0) launch_repair(projection, grid, st, a);     // every workgroup leaves at once unless a sample is flagged
     return check_launch();
 }
 

@@ -49,6 +49,9 @@ enum { BG_OPT_SUPG = 1,        /* include the SUPG vector (fom_burgers, pod_prom
        BG_OPT_MFMA_16X16 = 8,  /* bg_rom_reduce*: use the v_mfma_f64_16x16x4 kernel for every r (A/B timing, tests) */
        BG_OPT_FORCE_PIVOTED = 16 /* bg_rom_run: take the partial-pivoting branch of the reduced solve every time (tests) */ };
 
+/* transient value of bg_rom_run's info[b] between its two kernels (never seen by the caller) */
+#define BG_INFO_NEEDS_PIVOTING (-1)
+
 /* per-sample status bits written to `flags` */
 enum { BG_FLAG_HIT_CAP = 1, BG_FLAG_NONFINITE = 2 };
 
@@ -208,11 +211,13 @@ int bg_lu_solve_update(int n, int B, const double *A, const double *rhs, int mod
  *   Phi    [N][r] row-major (the reference's U_modes .npy layout), shared by all samples; N <= 512, r <= 40
  *          (bg_rom_run_max_r) -- beyond that use bg_rom_reduce + bg_lu_solve_update (BG_ERR_UNSUPPORTED_R / _N)
  *   u0, mu1, mu2, hist, iters, flags: as bg_fom_run (hist[b][0] = u0[b]; flags BG_FLAG_*)
- *   info   [B] or NULL: 0, or k+1 when the reduced matrix of a sample is exactly singular at elimination step k
+ *   info   [B] (required): 0, or k+1 when the reduced matrix of a sample is exactly singular at elimination step k
  *          (np.linalg.solve raises LinAlgError there); that sample stops and its remaining history is undefined
  *   options BG_OPT_SUPG (pod_prom_burgers has it) | BG_OPT_NONUNIFORM | BG_OPT_FORCE_PIVOTED
- *   The reduced solve is np.linalg.solve's partial-pivoting LU: as long as every multiplier stays <= 1 in modulus the
- *   pivot is the diagonal and no search is made; otherwise the system is redone with the pivot search of bg_lu_solve.
+ *   The reduced solve is np.linalg.solve's partial-pivoting elimination: as long as every multiplier stays <= 1 in
+ *   modulus the pivot is the diagonal and no search is made (first kernel).  A sample in which a multiplier exceeds 1
+ *   is marked in info and redone from u0 by a second kernel of the same call with the pivot search of bg_lu_solve;
+ *   that kernel returns at once when nothing is marked.  BG_OPT_FORCE_PIVOTED sends every sample through it.
  * --------------------------------------------------------------------------------- */
 int bg_rom_run_max_r(void);
 int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double *x, const double *Phi,
