@@ -27,7 +27,7 @@
 #include "rom_device.hpp"
 
 // Phase ablation for tools/time_fused.py (never defined in the product build): BG_FUSED_ABLATE is a bit mask of phases to
-// compile out (1 MFMA passes, 2 elimination, 4 back substitution, 8 lift, 16 assembly); the iteration count is then
+// compile out (1 MFMA passes, 2 elimination, 8 lift, 16 assembly, 32 MFMA epilogue, 64 per-step operand formation); the iteration count is then
 // fixed at 5 per time step and the pivoted fallback is disabled, so that the garbage values cannot change the control flow.
 #ifndef BG_FUSED_ABLATE
 #define BG_FUSED_ABLATE -1
@@ -87,15 +87,13 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const dou
         }
         X = (t == 0) ? R : ((t == 1) ? ui : 0.0);
     };
-    // Software pipeline: the operands of step s + 1 are formed (LDS reads + 3 NB VALU ops) between the MFMAs of step s,
-    // which leave the vector ALU idle for 12 of their 16 cycles; without it the two phases alternate (27 cycles per MFMA).
-    double Y[NB], X;
-    operands(0, Y, X);
-    __builtin_amdgcn_sched_barrier(0);
+    // No software pipelining here: measured (tools/mfma_valu_bench.hip) the fp64 4x4x4 MFMA does not overlap with vector
+    // ALU work of the same wave -- 110 MFMAs take 882 ns alone and 882 + 2.25 ns per interleaved v_fma_f64 -- so the
+    // phase costs the MFMAs plus every other instruction; interleaving only adds hazard s_nops (498 against 103).
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        double Yn[NB], Xn = 0.0;
-        if (s + 1 < S) operands(s + 1, Yn, Xn);
+        double Y[NB], X;
+        operands(skip(64) ? 0 : s, Y, X);        // (64: timing only)
         int p = 0;
         if constexpr (GAL) {
 #pragma unroll
@@ -120,20 +118,6 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const dou
                 for (int ca = 0; ca < NB; ++ca, ++p)
                     acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], X, acc[p], 0, 0, 0);
             }
-        }
-        if (s + 1 < S) {
-            // issue order of this step: the next step's LDS reads, a few MFMAs to cover their latency, then MFMA / VALU pairs
-            if (s + 1 == S - 1) __builtin_amdgcn_sched_group_barrier(0x100, 3 + NB, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-#pragma unroll
-            for (int q = 0; q < 3 * NB + 4; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-#pragma unroll
-            for (int c = 0; c < NB; ++c) Y[c] = Yn[c];
-            X = Xn;
         }
         __builtin_amdgcn_sched_barrier(0);       // nothing moves across a step: bounded register pressure
     }
@@ -181,9 +165,13 @@ template <int NB>
 __device__ __forceinline__ void lu_apply_block(double (&c)[4], const double (&m)[4], int p)
 {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int kk = 0; kk < 4; ++kk) {             // step-major: the eight readlanes of a step, then its four FMAs
+        double piv[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) c[t] = __builtin_fma(-m[kk], readlane_f64(c[t], 4 * p + kk), c[t]);
+        for (int t = 0; t < 4; ++t) piv[t] = readlane_f64(c[t], 4 * p + kk);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c[t] = __builtin_fma(-m[kk], piv[t], c[t]);
+    }
 }
 
 // factor the panel held in c[0..3] (columns 4p .. 4p+3, pivots in lanes 4p .. 4p+3); multipliers -> sm[kk][lane]
@@ -305,6 +293,8 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
         }
         __syncthreads();
 
+        const long long stamp0 = kTiming ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const long long real0 = kTiming ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
         int flags = 0, info_out = 0;
         bool aborted = false;                    // fast kernel: the multiplier guard tripped, the repair kernel redoes this sample
         for (int step = 0; step < a.nsteps && info_out == 0 && !aborted; ++step) {
@@ -343,10 +333,14 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                     s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = R;
                 }
                 __syncthreads();
-                // ---- projection on the matrix cores (Galerkin in two halves: 55 instead of 110 live accumulators) --
-                // two passes over the rows, each with half of the accumulators live (Galerkin 55 + 55, LSPG 45 + 30 at r = 40)
-                constexpr int CM = GAL ? NB / 2 : (NB + 1) / 3;
-                if constexpr (!skip(1)) {
+                // ---- projection on the matrix cores -----------------------------------------------------------------
+                // Galerkin: two passes over the rows with half of the (NB + 1) NB accumulators live in each (one pass spills at
+                // r = 40); LSPG: its NB (NB + 1) / 2 + 2 NB accumulators fit one pass, which forms the operands once.
+                constexpr int CM = GAL ? NB / 2 : 0;
+                if constexpr (skip(1)) {
+                } else if constexpr (CM == 0) {
+                    mfma_pass<S, NB, GAL, 0, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
+                } else {
                     mfma_pass<S, NB, GAL, 0, CM, false, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
                     mfma_pass<S, NB, GAL, CM, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
                 }
@@ -470,6 +464,10 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
         if (tid == 0) {
             a.flags[smp] = flags;
             a.info[smp] = aborted ? BG_INFO_NEEDS_PIVOTING : info_out;
+            if (kTiming && a.nsteps >= 2) {      // diagnostic builds only: shader cycles and 100 MHz ticks of this sample, in kilo-units
+                a.iters[(size_t)smp * a.nsteps] = (int)(((long long)__builtin_amdgcn_s_memtime() - stamp0) >> 10);
+                a.iters[(size_t)smp * a.nsteps + 1] = (int)(((long long)__builtin_amdgcn_s_memrealtime() - real0) >> 10);
+            }
         }
     }
 }

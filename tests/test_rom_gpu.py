@@ -85,7 +85,7 @@ def test_pod_prom_golden_and_live(hip):
     X, _ = mesh(512)
     for tag, proj in (("galerkin", "Galerkin"), ("lspg", "LSPG")):
         res = rom.pod_prom_run(X, np.ones(512), [4.75, float(live["mu1"])], [0.02, float(live["mu2"])], 0.05, 12,
-                               g["Phi"], projection=proj)
+                               g["Phi"], projection=proj, fused=False)  # host-driven path (the fused one: test_rom_fused_gpu.py)
         torch.cuda.synchronize()
         h = res.hist.cpu().numpy(); it = res.iters.cpu().numpy()
         assert rel_l2(h[0].T, g["first13_" + tag]) < TOL                # reference's committed .npy
@@ -96,7 +96,8 @@ def test_pod_prom_golden_and_live(hip):
         rom.pod_prom_run(X, np.ones(512), 4.75, 0.02, 0.05, 1, g["Phi"], projection="lspg")
 
 
-def test_pod_prom_batch_vs_oracle(hip):
+@pytest.mark.parametrize("fused", [False, True])
+def test_pod_prom_batch_vs_oracle(hip, fused):
     from burgers_hip import rom
     g = load_golden("committed_pod_r40.npz")
     rng = np.random.default_rng(3)
@@ -104,7 +105,7 @@ def test_pod_prom_batch_vs_oracle(hip):
     B = 12
     mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
     for proj in ("Galerkin", "LSPG"):
-        res = rom.pod_prom_run(X, np.ones(512), mu1, mu2, 0.05, 25, g["Phi"], projection=proj)
+        res = rom.pod_prom_run(X, np.ones(512), mu1, mu2, 0.05, 25, g["Phi"], projection=proj, fused=fused)
         torch.cuda.synchronize()
         h = res.hist.cpu().numpy(); it = res.iters.cpu().numpy()
         for b in range(B):

@@ -302,9 +302,11 @@ def _chunked(run, B, chunk=CHUNK):
     return (torch.cat([o.hist for o in outs]), torch.cat([o.iters for o in outs]), torch.cat([o.flags for o in outs]))
 
 
-def test_config3_pod_prom_b4096(hip):
+@pytest.mark.parametrize("fused", [True, False])
+def test_config3_pod_prom_b4096(hip, fused):
     """BASELINE configs[2]: POD-Galerkin / LSPG, r = 40, 4096 samples, N = 512 (a few time steps): bitwise
-    equal to 200-sample chunks, oracle on a strided subset, iteration counts identical."""
+    equal to 200-sample chunks, oracle on a strided subset, iteration counts identical -- through the device-side
+    time loop (bg_rom_run, 16 samples per workgroup) and through the host-driven batched iteration."""
     from burgers_hip import rom
     g = load_golden("committed_pod_r40.npz")
     rng = np.random.default_rng(20251121)
@@ -312,9 +314,9 @@ def test_config3_pod_prom_b4096(hip):
     B, nT = 4096, 6
     mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
     for proj in ("Galerkin", "LSPG"):
-        res = rom.pod_prom_run(X, np.ones(512), mu1, mu2, 0.05, nT, g["Phi"], projection=proj)
+        res = rom.pod_prom_run(X, np.ones(512), mu1, mu2, 0.05, nT, g["Phi"], projection=proj, fused=fused)
         h2, it2, fl2 = _chunked(lambda lo, hi: rom.pod_prom_run(X, np.ones(512), mu1[lo:hi], mu2[lo:hi], 0.05, nT, g["Phi"],
-                                                                projection=proj), B)
+                                                                projection=proj, fused=fused), B)
         torch.cuda.synchronize()
         assert torch.equal(res.iters, it2) and torch.equal(res.flags, fl2) and torch.equal(res.hist, h2), proj
         assert int(res.flags.abs().sum().item()) == 0

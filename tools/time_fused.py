@@ -29,8 +29,14 @@ best = 1e9
 for _ in range(3):
     e0.record(); res = run(); e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1))
+timing_build = "abl" in os.environ.get("BG_LIB_PATH", "")
+if timing_build:
+    st = res.iters[:, :2].double().cpu().numpy(); clk = np.median(st[:, 0] / st[:, 1]) * 100.0
+    res.iters[:, :2] = 5
 its = int(res.iters.sum().item())
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 waves = -(-a.batch // cus)
+if timing_build:
+    print(f"in-kernel clock (median over samples): {clk:.0f} MHz")
 print(f"{os.path.basename(os.environ.get('BG_LIB_PATH', 'product'))}: {a.proj} r={a.r} B={a.batch} steps={a.steps}: {best:.2f} ms, {its} sample-iterations, "
       f"{best * 1e3 / (its / a.batch * waves):.2f} us per sample-iteration per workgroup, {its / best * 1e3:.3g} sample-steps/s")
