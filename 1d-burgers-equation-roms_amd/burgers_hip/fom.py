@@ -69,11 +69,15 @@ def fom_run(X, u0, mu1, mu2, dt, nsteps, E=0.0, tol=1e-6, max_it=20, supg=True, 
     """Run B samples through ``nsteps`` implicit-Euler steps on the current HIP stream.
 
     X (N,), u0 (N,) or (B, N), mu1/mu2 scalar or (B,).  Returns a :class:`FomResult` of
-    device tensors; nothing is synchronised.
+    device tensors; nothing is synchronised.  ``out``: a FomResult whose tensors are reused as the
+    destination (shape, dtype, device and contiguity are checked: the kernel writes through raw pointers).
     """
     L = _lib.load()
     device = _lib.require_device(device)
     if options is None:
+        # validate_mesh=False skips the host round trip of X (a device tensor in a timed loop) and therefore ASSUMES the
+        # uniform mesh every driver of the reference builds (np.linspace); a caller with a graded mesh must pass
+        # ``options`` (BG_OPT_SUPG | BG_OPT_NONUNIFORM) or leave validate_mesh on
         options = _lib.mesh_options(check_mesh(X), supg) if validate_mesh else (_lib.BG_OPT_SUPG if supg else 0)
     Xd = _as_dev(X, device)
     N = Xd.numel()
@@ -85,6 +89,11 @@ def fom_run(X, u0, mu1, mu2, dt, nsteps, E=0.0, tol=1e-6, max_it=20, supg=True, 
         flags = torch.empty((B,), dtype=torch.int32, device=device)
     else:
         hist, iters, flags = out.hist, out.iters, out.flags
+        for name, t, shape, dt_ in (("hist", hist, (B, nsteps + 1, N), torch.float64), ("iters", iters, (B, nsteps), torch.int32),
+                                    ("flags", flags, (B,), torch.int32)):
+            if tuple(t.shape) != shape or t.dtype != dt_ or t.device != device or not t.is_contiguous():
+                raise ValueError(f"out.{name} must be a contiguous {dt_} tensor of shape {shape} on {device} "
+                                 f"(got {tuple(t.shape)}, {t.dtype}, {t.device})")
     with torch.cuda.device(device):
         rc = L.bg_fom_run(N, B, int(nsteps), _lib.ptr(Xd), _lib.ptr(u0d), _lib.ptr(mu1d), _lib.ptr(mu2d),
                           float(dt), float(E), float(tol), int(max_it), int(options),
@@ -141,7 +150,62 @@ def transpose_batched(t):
     return out
 
 
-def fd_run(a, b, N, u0, mu1, mu2, dt, nsteps, max_iter=30, tol=1e-8, device=None):
+def _fd_residual(U, Up, dt, dx, s_src):
+    """compute_residual (FD/fd_burgers.py:28-35) on the last axis; nu = 0.25 dx max|U| per state."""
+    nu = 0.25 * dx * U.abs().amax(dim=-1, keepdim=True)
+    R = torch.zeros_like(U)
+    conv = (0.5 * U[..., 2:] ** 2 - 0.5 * U[..., :-2] ** 2) / (2 * dx)
+    diff = nu * (U[..., 2:] - 2 * U[..., 1:-1] + U[..., :-2]) / dx ** 2
+    R[..., 1:-1] = (U[..., 1:-1] - Up[..., 1:-1]) / dt + conv - s_src[..., 1:-1] - diff
+    return R
+
+
+def _fd_run_fd_jacobian(a, b, N, u0d, mu1d, mu2d, dt, nsteps, max_iter, tol, device):
+    """The reference's debugging variant (FD/fd_burgers.py:46-57, ``use_fd_jacobian=True``): the Jacobian is formed by
+    one-sided differences of the residual (eps = 1e-8, the artificial viscosity re-evaluated per perturbed state), which
+    makes it DENSE -- there is no tridiagonal kernel to write.  Library path on the device: batched residuals of the
+    N - 2 perturbed states, one batched dense solve per Newton iteration, per-sample stopping as in :71-101."""
+    B = mu1d.numel()
+    dx = (b - a) / (N - 1)
+    x = torch.linspace(a, b, N, dtype=torch.float64, device=device)
+    s_src = 0.02 * torch.exp(mu2d[:, None] * x[None, :])                     # (B, N)
+    hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
+    iters = torch.zeros((B, nsteps), dtype=torch.int32, device=device)
+    flags = torch.zeros((B,), dtype=torch.int32, device=device)
+    eye = 1e-8 * torch.eye(N, dtype=torch.float64, device=device)[1:N - 1]   # (N-2, N)
+
+    def bc(U):
+        U = U.clone(); U[:, 0] = mu1d; U[:, -1] = U[:, -2]
+        return U
+
+    Uc = bc(u0d)
+    hist[:, 0] = Uc
+    for step in range(nsteps):
+        Up, Ug = Uc.clone(), Uc.clone()
+        active = torch.ones((B,), dtype=torch.bool, device=device)
+        k = torch.zeros((B,), dtype=torch.int32, device=device)
+        for _ in range(max_iter):
+            Ug = torch.where(active[:, None], bc(Ug), Ug)
+            R = _fd_residual(Ug, Up, dt, dx, s_src)
+            active = active & ~(R[:, 1:-1].abs().amax(dim=1) < tol)          # "Converged." on the residual (:77)
+            if not bool(active.any()):
+                break
+            Rp = _fd_residual(Ug[:, None, :] + eye[None], Up[:, None, :], dt, dx, s_src[:, None, :])   # (B, N-2, N)
+            J = ((Rp[:, :, 1:N - 1] - R[:, None, 1:N - 1]) / 1e-8).transpose(1, 2)                   # J[i, j] = dR_i/dU_j
+            dU = torch.zeros_like(Ug)
+            dU[:, 1:-1] = torch.linalg.solve(J, -R[:, 1:-1].unsqueeze(-1)).squeeze(-1)
+            rel = dU[:, 1:-1].abs().amax(dim=1) / Ug[:, 1:-1].abs().amax(dim=1).clamp_min(1e-15)
+            Ug = torch.where(active[:, None], Ug + dU, Ug)
+            k += active.to(torch.int32)
+            active = active & ~(rel < tol)
+        flags |= active.to(torch.int32) * _lib.BG_FLAG_HIT_CAP                # "did not converge within max_iter" (:97)
+        iters[:, step] = k
+        Uc = bc(Ug)
+        hist[:, step + 1] = Uc
+    return FomResult(hist, iters, flags)
+
+
+def fd_run(a, b, N, u0, mu1, mu2, dt, nsteps, max_iter=30, tol=1e-8, device=None, use_fd_jacobian=False):
     """Batched ``FDBurgers.fom_burgers_newton`` (FD/fd_burgers.py:59-107) on the mesh linspace(a, b, N)."""
     L = _lib.load()
     device = _lib.require_device(device)
@@ -151,6 +215,9 @@ def fd_run(a, b, N, u0, mu1, mu2, dt, nsteps, max_iter=30, tol=1e-8, device=None
     except ValueError as e:
         raise ValueError(str(e).replace("u0 has", "U0 has")) from None
     B = mu1d.numel()
+    if use_fd_jacobian:
+        return _fd_run_fd_jacobian(float(a), float(b), int(N), u0d, mu1d, mu2d, float(dt), int(nsteps), int(max_iter),
+                                   float(tol), device)
     hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
     iters = torch.empty((B, nsteps), dtype=torch.int32, device=device)
     flags = torch.empty((B,), dtype=torch.int32, device=device)

@@ -2,8 +2,8 @@
 
 Mirrors ``FDBurgers(a, b, N).fom_burgers_newton(dt, n_steps, U0, mu1, mu2, max_iter=30, tol=1e-8,
 use_fd_jacobian=False)`` (:59) on the MI355X through ``bg_fd_run``; ``mu1`` / ``mu2`` may be arrays
-of B samples (result ``(B, N, n_steps+1)``).  The finite-difference Jacobian option of the
-reference (:46-57, a debugging aid) is not reproduced.
+of B samples (result ``(B, N, n_steps+1)``).  ``use_fd_jacobian=True`` (the reference's debugging
+aid, :46-57) makes the Jacobian dense and runs as batched library calls on the device.
 """
 from __future__ import annotations
 
@@ -34,12 +34,9 @@ class FDBurgers:
         return 0.02 * np.exp(mu2 * self.x)
 
     def fom_burgers_newton(self, dt, n_steps, U0, mu1, mu2, max_iter=30, tol=1e-8, use_fd_jacobian=False):
-        if use_fd_jacobian:
-            raise NotImplementedError("the finite-difference Jacobian is a debugging aid of the reference; "
-                                      "the HIP path implements the analytical Jacobian")
         batched = np.ndim(mu1) > 0 or np.ndim(mu2) > 0 or np.ndim(U0) > 1
         res = _fom.fd_run(self.a, self.b, self.N, np.asarray(U0, dtype=np.float64), mu1, mu2, dt, int(n_steps),
-                          max_iter=max_iter, tol=tol)
+                          max_iter=max_iter, tol=tol, use_fd_jacobian=bool(use_fd_jacobian))
         U = _lib.to_host(res.snapshots())
         self.last_iters = res.iters.cpu().numpy()
         self.last_flags = res.flags.cpu().numpy()

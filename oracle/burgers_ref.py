@@ -506,10 +506,33 @@ def predict_on_fom_grid(mu1, mu2, Nt, U_modes, weights, biases, mean, std):
 # --------------------------------------------------------------------------
 # Finite-difference true-Newton stepper          (FD/fd_burgers.py:14-107)
 # --------------------------------------------------------------------------
-def fd_newton(a, b, N, dt, n_steps, U0, mu1, mu2, max_iter=30, tol=1e-8, return_iters=False):
-    """``FDBurgers.fom_burgers_newton`` (analytical Jacobian): central differences, lagged
-    artificial viscosity ``nu = 0.25 dx max|U|``, backward Euler, Newton with the tridiagonal
-    Jacobian of FD/fd_burgers.py:36-43, stop on max residual or max relative update < tol."""
+def _fd_residual(U, Up, dt, dx, s_src):
+    """compute_residual (FD/fd_burgers.py:28-35) on the last axis of U (any leading batch axes)."""
+    nu = 0.25 * dx * np.max(np.abs(U), axis=-1, keepdims=True)
+    R = np.zeros_like(U)
+    conv = (0.5 * U[..., 2:] ** 2 - 0.5 * U[..., :-2] ** 2) / (2 * dx)
+    diff = nu * (U[..., 2:] - 2 * U[..., 1:-1] + U[..., :-2]) / dx ** 2
+    R[..., 1:-1] = (U[..., 1:-1] - Up[1:-1]) / dt + conv - s_src[1:-1] - diff
+    return R
+
+
+def fd_jacobian_fd(U, Up, dt, dx, s_src, epsilon=1e-8):
+    """compute_jacobian_fd (FD/fd_burgers.py:46-57): one-sided differences of the residual, column by column; the
+    artificial viscosity is re-evaluated for every perturbed state, so the matrix is dense in the row of max|U|."""
+    N = len(U)
+    Rb = _fd_residual(U, Up, dt, dx, s_src)
+    Upert = U[None, :] + epsilon * np.eye(N)[1:N - 1]                 # row j-1: U with U[j] += eps
+    Rp = _fd_residual(Upert, Up, dt, dx, s_src)
+    J = np.zeros((N, N))
+    J[1:N - 1, 1:N - 1] = ((Rp[:, 1:N - 1] - Rb[None, 1:N - 1]) / epsilon).T
+    return J
+
+
+def fd_newton(a, b, N, dt, n_steps, U0, mu1, mu2, max_iter=30, tol=1e-8, return_iters=False, use_fd_jacobian=False):
+    """``FDBurgers.fom_burgers_newton``: central differences, lagged artificial viscosity
+    ``nu = 0.25 dx max|U|``, backward Euler, Newton with the tridiagonal analytical Jacobian of
+    FD/fd_burgers.py:36-43 (or, ``use_fd_jacobian``, the dense finite-difference one of :46-57 and a dense solve),
+    stop on max residual or max relative update < tol."""
     dx = (b - a) / (N - 1)
     x = np.linspace(a, b, N)
     s_src = 0.02 * np.exp(mu2 * x)
@@ -531,6 +554,16 @@ def fd_newton(a, b, N, dt, n_steps, U0, mu1, mu2, max_iter=30, tol=1e-8, return_
             R[1:-1] = (Ug[1:-1] - Up[1:-1]) / dt + conv - s_src[1:-1] - diff
             if np.max(np.abs(R[1:-1])) < tol:
                 break
+            if use_fd_jacobian:
+                J = fd_jacobian_fd(Ug, Up, dt, dx, s_src)
+                dU = np.zeros(N)
+                dU[1:-1] = np.linalg.solve(J[1:-1, 1:-1], -R[1:-1])
+                rel = np.max(np.abs(dU[1:-1])) / max(np.max(np.abs(Ug[1:-1])), 1e-15)
+                Ug = Ug + dU
+                k += 1
+                if rel < tol:
+                    break
+                continue
             lo = np.zeros(N); di = np.ones(N); up = np.zeros(N)
             lo[1:-1] = -Ug[:-2] / (2 * dx) - nu / dx ** 2
             up[1:-1] = Ug[2:] / (2 * dx) - nu / dx ** 2

@@ -287,6 +287,11 @@ def fx_fd():
         U, log = quiet(fd.fom_burgers_newton, dt, nT, np.ones(N), mu1, mu2)
         its = np.array([blk.count("relative update") for blk in log.split("Time step")[1:]], dtype=np.int32)
         out.update({f"U_{tag}": U, f"iters_{tag}": its, f"par_{tag}": np.array([N, dt, nT, mu1, mu2])})
+    # the finite-difference Jacobian option (FD/fd_burgers.py:46-57), a small case: the matrix is dense
+    fd = fd_burgers.FDBurgers(0.0, 100.0, 64)
+    U, log = quiet(fd.fom_burgers_newton, 0.1, 5, np.ones(64), 4.7, 0.02, use_fd_jacobian=True)
+    out["U_fdjac_n64"] = U
+    out["iters_fdjac_n64"] = np.array([blk.count("relative update") for blk in log.split("Time step")[1:]], dtype=np.int32)
     c = np.load(os.path.join(REF, "FD/fd_training_data/fd_simulation_mu1_4.250_mu2_0.0150.npy"))
     out["committed_first11"] = c[:, :11]
     out["committed_cols"] = c[:, COLS]

@@ -239,8 +239,6 @@ def test_fd_newton_stepper(hip):
             Uo, ito = br.fd_newton(0.0, 100.0, N, dt, 12, u0[b], mu1[b], mu2[b], return_iters=True)
             assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < TOL, (N, b)
             assert np.array_equal(res.iters[b].cpu().numpy(), ito), (N, b)
-    with pytest.raises(NotImplementedError):
-        fd.fom_burgers_newton(0.05, 1, np.ones(512), 4.25, 0.015, use_fd_jacobian=True)
 
 
 @pytest.mark.parametrize("N", [1100, 1536, 2048])
@@ -433,3 +431,58 @@ def test_facade_batch_broadcasting(hip):
     with pytest.raises(ValueError):
         fem.pod_prom_burgers(0.05, 3, u0, np.array([4.5, 4.6]), 0.0, np.array([0.02, 0.03, 0.04]), Phi)
     assert fem.pod_prom_burgers(0.05, 3, u0, 4.5, 0.0, 0.02, np.asfortranarray(Phi)).shape == (N, 4)
+
+
+def test_out_buffers_are_validated(hip):
+    """fom_run(out=...) hands raw pointers to the kernel: a buffer of the wrong shape / dtype / layout is refused."""
+    from burgers_hip import fom
+    X, _ = mesh(64)
+    ok = fom.FomResult(torch.empty((3, 5, 64), dtype=torch.float64, device="cuda"),
+                       torch.empty((3, 4), dtype=torch.int32, device="cuda"), torch.empty((3,), dtype=torch.int32, device="cuda"))
+    fom.fom_run(X, np.ones(64), [4.5, 5.0, 5.2], 0.02, 0.05, 4, out=ok)
+    for bad in (fom.FomResult(ok.hist[:, :4], ok.iters, ok.flags),                                  # too few time levels
+                fom.FomResult(ok.hist, ok.iters.to(torch.int64), ok.flags),                         # wrong dtype
+                fom.FomResult(ok.hist.transpose(1, 2).contiguous().transpose(1, 2), ok.iters, ok.flags),   # not contiguous
+                fom.FomResult(ok.hist.cpu(), ok.iters, ok.flags)):                                  # wrong device
+        with pytest.raises(ValueError):
+            fom.fom_run(X, np.ones(64), [4.5, 5.0, 5.2], 0.02, 0.05, 4, out=bad)
+
+
+def test_failed_launch_reports_the_hip_error(hip):
+    """Every entry point records the hipError_t of a failed launch (one check_launch for all translation units): a
+    launch on a stream handle that is not a stream fails, and bg_last_hip_error() is non-zero afterwards.  Run in a
+    child process: what a runtime does with a bad handle is its own business, the parent must not depend on it."""
+    import subprocess, sys
+    from conftest import PKG
+    code = (
+        "import sys, ctypes; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from burgers_hip import lib\n"
+        "L = lib.load()\n"
+        "t = torch.zeros((4, 4), dtype=torch.float32, device='cuda')\n"
+        "bad = torch.zeros(64, dtype=torch.int64, device='cpu')          # host memory that is no hipStream_t\n"
+        "rc = L.bg_mlp_act_jvp(1, 4, 4, lib.ptr(t), None, lib.BG_ACT_RELU, 1.0, ctypes.c_void_p(bad.data_ptr()))\n"
+        "print('RC', rc, L.bg_last_hip_error())\n" % PKG)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RC")]
+    if out.returncode != 0 or not line:
+        pytest.skip("the HIP runtime does not survive an invalid stream handle: " + out.stderr[-200:])
+    rc, err = map(int, line[0].split()[1:])
+    if rc == hip.BG_OK:
+        pytest.skip("the HIP runtime accepted the handle")
+    assert rc == hip.BG_ERR_LAUNCH and err != 0
+
+
+def test_fd_jacobian_option(hip):
+    """FDBurgers.fom_burgers_newton(use_fd_jacobian=True) (FD/fd_burgers.py:46-57): dense finite-difference Jacobian,
+    library path on the device; against the live-reference fixture and the oracle on a batch."""
+    from fd_burgers import FDBurgers
+    g = load_golden("fd_newton.npz")
+    fd = FDBurgers(0.0, 100.0, 64)
+    U = fd.fom_burgers_newton(0.1, 5, np.ones(64), 4.7, 0.02, use_fd_jacobian=True)
+    assert U.shape == (64, 6) and rel_l2(U, g["U_fdjac_n64"]) < 1e-9 and np.array_equal(fd.last_iters, g["iters_fdjac_n64"])
+    mu1 = np.array([4.3, 5.0, 5.4]); mu2 = np.array([0.016, 0.022, 0.029])
+    Ub = fd.fom_burgers_newton(0.1, 4, np.ones(64), mu1, mu2, use_fd_jacobian=True)
+    for b in range(3):
+        Uo, ito = br.fd_newton(0.0, 100.0, 64, 0.1, 4, np.ones(64), mu1[b], mu2[b], return_iters=True, use_fd_jacobian=True)
+        assert rel_l2(Ub[b], Uo) < 1e-9 and np.array_equal(fd.last_iters[b], ito)      # eps = 1e-8 differences: 1e-9, not 1e-10

@@ -140,6 +140,8 @@ def test_fd_newton_live_and_committed():
         N, dt, nT, mu1, mu2 = g["par_" + tag]
         U, it = br.fd_newton(0.0, 100.0, int(N), dt, int(nT), np.ones(int(N)), mu1, mu2, return_iters=True)
         assert rel_l2(U, g["U_" + tag]) < 1e-14 and np.array_equal(it, g["iters_" + tag])
+    U, it = br.fd_newton(0.0, 100.0, 64, 0.1, 5, np.ones(64), 4.7, 0.02, return_iters=True, use_fd_jacobian=True)
+    assert rel_l2(U, g["U_fdjac_n64"]) < 1e-13 and np.array_equal(it, g["iters_fdjac_n64"])     # dense FD Jacobian (:46-57)
     U = br.fd_newton(0.0, 100.0, 512, 0.05, 10, np.ones(512), 4.25, 0.015)
     assert rel_l2(U, g["committed_first11"]) < 1e-14        # FD/fd_training_data (committed by the reference)
 

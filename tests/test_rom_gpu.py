@@ -282,7 +282,9 @@ def test_nonintrusive_decoder_fp32_and_bf16(hip):
     Ub = decoder.predict_on_grid(float(g["mu1"]), float(g["mu2"]), int(g["Nt"]), g["U_modes"], copy.deepcopy(model),
                                  g["mean"], g["std"], dtype=torch.bfloat16)
     err = rel_l2(Ub[0].cpu().numpy()[:, g["cols"]], g["Uhat_cols"])
-    assert err < 5e-2, err                                           # bf16 tier: reported, loosely bounded
+    # bf16 tier of config 5: MEASURED 6.0e-3 .. 6.8e-3 over the bench's mu range (tools/measure_config5.py: 8-bit
+    # significands through a 4-layer MLP and a 160-term contraction); gated at about twice that
+    assert 1e-3 < err < 1.5e-2, err
 
 
 def test_pod_rbf_prom_live_reference(hip):
@@ -399,7 +401,9 @@ def test_rom_edge_cases_and_bf16_tier(hip):
     low = rom.pod_ann_run(X, np.ones(512), 4.56, 0.019, 0.05, 3, a["U_p"], a["U_s"], model, ann_dtype=torch.bfloat16)
     torch.cuda.synchronize()
     err = rel_l2(low.hist[0].cpu().numpy(), ref.hist[0].cpu().numpy())
-    assert np.isfinite(low.hist.cpu().numpy()).all() and err < 0.2, err     # bf16 has 8 significant bits
+    # bf16 closure inside the Newton loop: MEASURED 0.6 % .. 2.2 % relative to the float32 closure over the bench's mu range
+    # (tools/measure_config5.py); gated at about twice the largest value
+    assert np.isfinite(low.hist.cpu().numpy()).all() and err < 5e-2, err
 
 
 def test_rom_reduce_randomised_sizes(hip):
@@ -582,3 +586,38 @@ def test_both_mfma_kernels_agree(hip):
                 out.append((Ar.cpu().numpy(), brr.cpu().numpy(), wtu.cpu().numpy()))
             for a, b in zip(*out):
                 assert rel_l2(a, b) < 1e-13
+
+
+def test_closure_roms_cap_pattern_matches_the_oracle(hip):
+    """bench.py --config ann reports about half of its samples with BG_FLAG_HIT_CAP.  That is the algorithm, not the
+    kernels: on the bench's own (mu1, mu2) draw the oracle runs into the 50-iteration cap on exactly the same samples
+    and time steps (the first step of the samples with mu1 > 4.9), and the POD-RBF closure into its 30-iteration cap
+    likewise.  POD-ANN iteration counts may differ by one where float32 noise sits on the threshold."""
+    import bench
+    from burgers_hip import rom
+    from test_rom_large_batch_gpu import _ann_model
+    X, _ = mesh(512)
+    mu1a, mu2a = bench.mu_shard(2048, 1, 0)
+    idx = np.linspace(0, 2047, 8).astype(int)
+    mu1, mu2 = mu1a[idx], mu2a[idx]
+    g = load_golden("ann_n5.npz")
+    nT = 12
+    res = rom.pod_ann_run(X, np.ones(512), mu1, mu2, 0.05, nT, g["U_p"], g["U_s"], _ann_model(g))
+    torch.cuda.synchronize()
+    Ws = [g[f"W{i}"] for i in range(6)]; bs = [g[f"b{i}"] for i in range(6)]
+    it = res.iters.cpu().numpy(); fl = res.flags.cpu().numpy()
+    capped = 0
+    for b in range(len(idx)):
+        Uo, ito = br.pod_ann_prom(X, 0.05, nT, np.ones(512), mu1[b], 0.0, mu2[b], g["U_p"], g["U_s"], Ws, bs, return_iters=True)
+        assert np.array_equal(it[b] >= 50, ito >= 50), b                        # same capped steps
+        assert bool(fl[b] & 1) == bool((ito >= 50).any()) and np.abs(it[b] - ito).max() <= 1
+        assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < 5e-6
+        capped += int((ito >= 50).any())
+    assert 0 < capped < len(idx)                                                # the draw has both kinds
+    r = load_golden("rbf_n17.npz")
+    cl = (r["U_p"], r["U_s"], r["X_train"], r["W_gaussian"], float(r["eps_gaussian"]), r["x_min"], r["x_max"], r["y_min"], r["y_max"])
+    res = rom.pod_rbf_run(X, np.ones(512), mu1[:4], mu2[:4], 0.05, nT, *cl)
+    torch.cuda.synchronize()
+    for b in range(4):
+        Uo, ito = br.pod_rbf_prom(X, 0.05, nT, np.ones(512), mu1[b], 0.0, mu2[b], *cl, return_iters=True)
+        assert np.array_equal(res.iters[b].cpu().numpy(), ito) and rel_l2(res.hist[b].cpu().numpy().T, Uo) < 1e-9
