@@ -282,7 +282,7 @@ def test_nonintrusive_decoder_fp32_and_bf16(hip):
     Ub = decoder.predict_on_grid(float(g["mu1"]), float(g["mu2"]), int(g["Nt"]), g["U_modes"], copy.deepcopy(model),
                                  g["mean"], g["std"], dtype=torch.bfloat16)
     err = rel_l2(Ub[0].cpu().numpy()[:, g["cols"]], g["Uhat_cols"])
-    # bf16 tier of config 5: MEASURED 6.0e-3 .. 6.8e-3 over the bench's mu range (tools/measure_config5.py: 8-bit
+    # bf16 tier of config 5: MEASURED 6.0e-3 .. 6.8e-3 over the bench's mu range (tests/fuzz/measure_config5.py: 8-bit
     # significands through a 4-layer MLP and a 160-term contraction); gated at about twice that
     assert 1e-3 < err < 1.5e-2, err
 
@@ -402,7 +402,7 @@ def test_rom_edge_cases_and_bf16_tier(hip):
     torch.cuda.synchronize()
     err = rel_l2(low.hist[0].cpu().numpy(), ref.hist[0].cpu().numpy())
     # bf16 closure inside the Newton loop: MEASURED 0.6 % .. 2.2 % relative to the float32 closure over the bench's mu range
-    # (tools/measure_config5.py); gated at about twice the largest value
+    # (tests/fuzz/measure_config5.py); gated at about twice the largest value
     assert np.isfinite(low.hist.cpu().numpy()).all() and err < 5e-2, err
 
 
