@@ -31,7 +31,8 @@ if stats:
             r[0] = short(r[0]); w.writerow(r)
             if key in r[0]:
                 avg_ns = float(r[3])
-summary = {"round": tag, "kernel": key, "avg_ns_kernel_trace": avg_ns}
+summary = {"round": tag, "kernel": key, "avg_ns_kernel_trace": avg_ns,
+           "config": {"config": "fom", "batch": 1024, "n": 1024, "time_steps": 500, "dt": 0.025}}     # what tools/profile_fom.sh runs
 pm = {}
 with open(os.path.join(dst, f"{tag}_pmc.csv"), "w", newline="") as f:
     w = csv.writer(f); w.writerow(["counter", "dispatch_id", "value_KiB", "vgpr", "sgpr", "lds", "scratch", "duration_ns"])

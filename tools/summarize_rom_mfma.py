@@ -10,13 +10,13 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sorted(glob.glob(os.path.join(REPO, "gpurun_out", "rom_mfma", "pmc", "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1]
-rows = list(csv.DictReader(open(src)))
+src = sorted(glob.glob(os.path.join(REPO, "gpurun_out", "rom_mfma", "pmc", "*", "*_counter_collection.csv")), key=os.path.getmtime)
+rows = [r for f in src for r in csv.DictReader(open(f))]          # both bench runs (Galerkin, LSPG)
 per = defaultdict(lambda: defaultdict(dict))          # kernel -> dispatch -> counter -> value
 meta = {}
 for r in rows:
     k = r["Kernel_Name"]
-    if "rom_reduce" not in k and "lu_solve" not in k:
+    if "rom_reduce" not in k and "lu_solve" not in k and "rom_fused" not in k:
         continue
     d = r["Dispatch_Id"]
     per[k][d][r["Counter_Name"]] = float(r["Counter_Value"])
@@ -32,7 +32,7 @@ for k, disp in per.items():
     dur = sum(meta[(k, d)][1] for d in keep) / n
     mfma_busy, cu_busy = mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("SQ_BUSY_CU_CYCLES")
     mops = mean("SQ_INSTS_VALU_MFMA_MOPS_F64")
-    out.append({"kernel": (re.search(r"(rom_reduce\w*<[^>]*>|lu_solve_kernel<[^>]*>)", k) or [k[:80]])[0], "launches": n, "avg_us": dur / 1e3,
+    out.append({"kernel": (re.search(r"(rom_reduce\w*<[^>]*>|lu_solve_kernel<[^>]*>|rom_fused_kernel<[^>]*>)", k) or [k[:80]])[0], "launches": n, "avg_us": dur / 1e3,
                 "SQ_VALU_MFMA_BUSY_CYCLES": mfma_busy, "SQ_BUSY_CU_CYCLES": cu_busy,
                 "MfmaUtil": mfma_busy / (4.0 * cu_busy) if cu_busy else None,
                 "SQ_INSTS_VALU_MFMA_MOPS_F64": mops, "SQ_INSTS_VALU_MFMA_F64": mean("SQ_INSTS_VALU_MFMA_F64"),
