@@ -174,19 +174,27 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void tridiag_solve_kernel(Sol
 }
 
 // ---- workgroup-per-sample variants (2048 < N <= 8192), see fom_wide.hpp ---------------------
+// PARK (uniform mesh, 32 rows per thread): g and hfs live in LDS (WidePark) instead of 128 VGPRs per thread.
 template <int R, bool UNI>
 __global__ __launch_bounds__(WIDE_THREADS, 1) void fom_wide_kernel(FomArgs a)
 {
+    constexpr bool PARK = UNI && R >= 32;
     __shared__ WideLds lds;
+    __shared__ WidePark<PARK ? R : 1> park;
     const int g = threadIdx.x, s = blockIdx.x;              // one workgroup per sample
     const int N = a.N, row0 = g * R;
     wide_init(lds, g);
     const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
     const MeshConst c = make_mesh_const(h, a.dt, a.E, a.supg);
     const double mu1 = a.mu1[s], mu2 = a.mu2[s];
-    double hfs[R], fdt[R], u[R], gv[R];
+    double hfs[PARK ? 1 : R], fdt[R], u[R], gv[PARK ? 1 : R];
     ElemGeom<UNI ? 0 : R> gm;
-    if constexpr (UNI) {
+    if constexpr (PARK) {
+        double hf[R];
+        forcing_setup<R>(a.x, N, row0, mu2, c.h, a.dt, hf, fdt);
+#pragma unroll
+        for (int j = 0; j < R; ++j) park.hfs[j][g] = hf[j];
+    } else if constexpr (UNI) {
         forcing_setup<R>(a.x, N, row0, mu2, c.h, a.dt, hfs, fdt);
     } else {
         geom_setup<R>(a.x, N, row0, a.dt, a.E, gm);
@@ -197,13 +205,15 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void fom_wide_kernel(FomArgs a)
     store_rows<R>(hist, N, row0, false, u);
     int flags = 0;
     for (int step = 0; step < a.nsteps; ++step) {
-        if constexpr (UNI) wide_mass_rhs_uni<R>(lds, g, c, N, u, fdt, gv);
+        if constexpr (PARK) wide_mass_rhs_uni_parked<R>(lds, park, g, c, N, u, fdt);
+        else if constexpr (UNI) wide_mass_rhs_uni<R>(lds, g, c, N, u, fdt, gv);
         else wide_mass_rhs<R>(lds, g, gm, N, u, fdt, gv);
         int k = 0;
         bool more;                                          // workgroup-uniform: every thread sees the same sums
         do {
             double lo[R], di[R], up[R], rhs[R];
-            if constexpr (UNI) wide_assemble_uni<R>(lds, g, c, N, mu1, u, gv, hfs, lo, di, up, rhs);
+            if constexpr (PARK) wide_assemble_uni_parked<R>(lds, park, g, c, N, mu1, u, lo, di, up, rhs);
+            else if constexpr (UNI) wide_assemble_uni<R>(lds, g, c, N, mu1, u, gv, hfs, lo, di, up, rhs);
             else wide_assemble<R>(lds, g, gm, a.dt, c.kap, N, mu1, u, gv, hfs, lo, di, up, rhs);
             wide_tridiag_solve<R>(lds, g, lo, di, up, rhs);
             double nd = 0.0, nu = 0.0;

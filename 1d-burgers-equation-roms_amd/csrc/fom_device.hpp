@@ -83,9 +83,10 @@ __device__ __forceinline__ void forcing_setup(const double* __restrict__ x, int 
 
 // g = M u^n + dt F  (constant over the Picard iterations of one time step).  uL / uR: u of the row below
 // this lane's first row / above its last row (0 outside the mesh).
-template <int R, bool FULL>
-__device__ __forceinline__ void mass_rhs_core(const MeshConst& c, int N, int row0, const double (&u)[R], double uL,
-                                              double uR, const double (&fdt)[R], double (&g)[R])
+// gstore(j, value): where row j of g goes (registers, or LDS when a kernel parks it there)
+template <int R, bool FULL, typename GStore>
+__device__ __forceinline__ void mass_rhs_core_to(const MeshConst& c, int N, int row0, const double (&u)[R], double uL,
+                                                 double uR, const double (&fdt)[R], GStore&& gstore)
 {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -95,8 +96,15 @@ __device__ __forceinline__ void mass_rhs_core(const MeshConst& c, int N, int row
         double inner = __builtin_fma(4.0, u[j], um) + up;
         double last = __builtin_fma(2.0, u[j], um);
         double v = __builtin_fma(c.h6, (i == N - 1) ? last : inner, fdt[j]);
-        g[j] = (!FULL && i >= N) ? 0.0 : v;
+        gstore(j, (!FULL && i >= N) ? 0.0 : v);
     }
+}
+
+template <int R, bool FULL>
+__device__ __forceinline__ void mass_rhs_core(const MeshConst& c, int N, int row0, const double (&u)[R], double uL,
+                                              double uR, const double (&fdt)[R], double (&g)[R])
+{
+    mass_rhs_core_to<R, FULL>(c, N, row0, u, uL, uR, fdt, [&](int j, double v) { g[j] = v; });
 }
 
 template <int R, bool FULL>
@@ -110,10 +118,10 @@ __device__ __forceinline__ void mass_rhs(const MeshConst& c, int N, int row0, co
 // the halo values can come from DPP (one wave per sample) or LDS (one workgroup per sample).
 // p1: off-diagonals and the SUPG element terms se[];  p2: diagonal, right-hand side, special rows.
 // `first` / `last_lane` mark the lanes that own global row 0 / (FULL only) the last row.
-template <int R>
-__device__ __forceinline__ void assemble_p1(const MeshConst& c, const double (&u)[R], double uL, double uR,
-                                            const double (&hfs)[R], double (&lo)[R], double (&up)[R],
-                                            double (&se)[R])
+// hf(j): hfs of local row j (a register array, or an LDS read when a kernel parks it there)
+template <int R, typename HF>
+__device__ __forceinline__ void assemble_p1_from(const MeshConst& c, const double (&u)[R], double uL, double uR,
+                                                 HF&& hf, double (&lo)[R], double (&up)[R], double (&se)[R])
 {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -123,17 +131,25 @@ __device__ __forceinline__ void assemble_p1(const MeshConst& c, const double (&u
         up[j] = __builtin_fma(c.dt6, w + u[j], c.aoff);
         if (j + 1 < R) lo[j + 1] = __builtin_fma(-c.dt6, w + ur, c.aoff);
         const double mx = fmax(fabs(w), 2.0e-10);
-        const double t = __builtin_fma(w, dif, -hfs[j]);
+        const double t = __builtin_fma(w, dif, -hf(j));
         se[j] = t * BG_RCP(mx);
     }
     lo[0] = __builtin_fma(-c.dt6, __builtin_fma(2.0, u[0], uL), c.aoff);
 }
 
-template <int R, bool FULL>
-__device__ __forceinline__ void assemble_p2(const MeshConst& c, int N, int row0, bool first, bool last_lane,
-                                            double mu1, const double (&u)[R], double uL, double uR, double seL,
-                                            const double (&g)[R], const double (&se)[R], double (&lo)[R],
-                                            double (&di)[R], double (&up)[R], double (&rhs)[R])
+template <int R>
+__device__ __forceinline__ void assemble_p1(const MeshConst& c, const double (&u)[R], double uL, double uR,
+                                            const double (&hfs)[R], double (&lo)[R], double (&up)[R],
+                                            double (&se)[R])
+{
+    assemble_p1_from<R>(c, u, uL, uR, [&](int j) { return hfs[j]; }, lo, up, se);
+}
+
+template <int R, bool FULL, typename GF>
+__device__ __forceinline__ void assemble_p2_from(const MeshConst& c, int N, int row0, bool first, bool last_lane,
+                                                 double mu1, const double (&u)[R], double uL, double uR, double seL,
+                                                 GF&& g, const double (&se)[R], double (&lo)[R],
+                                                 double (&di)[R], double (&up)[R], double (&rhs)[R])
 {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -142,7 +158,7 @@ __device__ __forceinline__ void assemble_p2(const MeshConst& c, int N, int row0,
         const double sm = (j == 0) ? seL : se[j - 1];
         const int i = row0 + j;
         double d = __builtin_fma(c.dt6, um - ur, c.dd2);
-        double b = __builtin_fma(-c.kap, sm, g[j]);
+        double b = __builtin_fma(-c.kap, sm, g(j));
         double bb = __builtin_fma(c.kap, se[j], b);
         double l = lo[j], p = up[j];
         // special rows: last real row has no right element; rows >= N are identity
@@ -171,6 +187,16 @@ __device__ __forceinline__ void assemble_p2(const MeshConst& c, int N, int row0,
         r = __builtin_fma(-p, ur, r);
         lo[j] = l; di[j] = d; up[j] = p; rhs[j] = r;
     }
+}
+
+template <int R, bool FULL>
+__device__ __forceinline__ void assemble_p2(const MeshConst& c, int N, int row0, bool first, bool last_lane,
+                                            double mu1, const double (&u)[R], double uL, double uR, double seL,
+                                            const double (&g)[R], const double (&se)[R], double (&lo)[R],
+                                            double (&di)[R], double (&up)[R], double (&rhs)[R])
+{
+    assemble_p2_from<R, FULL>(c, N, row0, first, last_lane, mu1, u, uL, uR, seL, [&](int j) { return g[j]; }, se, lo, di,
+                              up, rhs);
 }
 
 template <int R, bool FULL>

@@ -73,6 +73,41 @@ __device__ __forceinline__ void wide_assemble(WideLds& s, int g, const ElemGeom<
     assemble_general_p2<R>(gm, dt, kap, N, g * R, g == 0, mu1, u, uL, uR, seL, gv, se, lo, di, up, rhs);
 }
 
+// Parked rows: at 32 rows per thread the per-row constants of a whole time step, g = M u^n + dt F and hfs, no longer fit
+// the register file beside the solver's working set (404 bytes of scratch per thread).  The uniform-mesh N > 6144 kernel
+// keeps them in LDS instead, row-major over threads (park[j][g]: consecutive threads, consecutive addresses) and reads
+// each value where the assembly uses it.
+template <int R>
+struct WidePark {
+    double g[R][WIDE_THREADS];
+    double hfs[R][WIDE_THREADS];
+};
+
+template <int R>
+__device__ __forceinline__ void wide_mass_rhs_uni_parked(WideLds& s, WidePark<R>& pk, int g, const MeshConst& c, int N,
+                                                         const double (&u)[R], const double (&fdt)[R])
+{
+    double uL, uR;
+    wide_halo_u<R>(s, g, u, uL, uR);
+    mass_rhs_core_to<R, false>(c, N, g * R, u, uL, uR, fdt, [&](int j, double v) { pk.g[j][g] = v; });
+    __syncthreads();
+}
+
+template <int R>
+__device__ __forceinline__ void wide_assemble_uni_parked(WideLds& s, const WidePark<R>& pk, int g, const MeshConst& c, int N,
+                                                         double mu1, const double (&u)[R], double (&lo)[R], double (&di)[R],
+                                                         double (&up)[R], double (&rhs)[R])
+{
+    double uL, uR, se[R];
+    wide_halo_u<R>(s, g, u, uL, uR);
+    assemble_p1_from<R>(c, u, uL, uR, [&](int j) { return pk.hfs[j][g]; }, lo, up, se);
+    s.se[g + WIDE_PAD] = se[R - 1];
+    __syncthreads();
+    const double seL = s.se[g + WIDE_PAD - 1];
+    assemble_p2_from<R, false>(c, N, g * R, g == 0, false, mu1, u, uL, uR, seL, [&](int j) { return pk.g[j][g]; }, se, lo,
+                               di, up, rhs);
+}
+
 // uniform-mesh variants (one element length: no per-element registers, fewer instructions)
 template <int R>
 __device__ __forceinline__ void wide_mass_rhs_uni(WideLds& s, int g, const MeshConst& c, int N, const double (&u)[R],
