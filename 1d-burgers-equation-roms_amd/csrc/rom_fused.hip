@@ -377,25 +377,33 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                     bool zero_piv = false;
                     if (w == 0) lu_factor_panel(lu.col[0], 0, lane, s_m[0], gmax, zero_piv);
                     __syncthreads();
+                    double mprev[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int p = 0; p < (skip(2) ? 0 : NB); ++p) {
                         double m[4];
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) m[kk] = s_m[p & 1][kk][lane];
                         const int nxt = p + 1;
-                        if (nxt < NB && w == (nxt & 3)) {                         // look-ahead: next panel first
+                        const bool owner_next = nxt < NB && w == (nxt & 3);
+                        const bool owner_this = p > 0 && w == (p & 3);       // deferred panel p - 1 for its later blocks
+                        if (owner_next) {                                     // look-ahead: next panel first ...
                             lu_apply_block<NB>(lu.col[nxt >> 2], m, p);
                             lu_factor_panel(lu.col[nxt >> 2], nxt, lane, s_m[nxt & 1], gmax, zero_piv);
                         }
 #pragma unroll
                         for (int s = 0; s < NSLOT; ++s) {
                             const int b = w + 4 * s;
-                            if (b > p && b < NB && b != nxt) lu_apply_block<NB>(lu.col[s], m, p);
+                            if (b > p && b < NB && b != nxt && !owner_next) {   // ... and its other blocks one panel later,
+                                if (owner_this) lu_apply_block<NB>(lu.col[s], mprev, p - 1);   // so that no wave carries
+                                lu_apply_block<NB>(lu.col[s], m, p);                           // factor + three updates
+                            }
                         }
                         if (w == 3) {
 #pragma unroll
                             for (int kk = 0; kk < 4; ++kk) lu.rhs = __builtin_fma(-m[kk], readlane_f64(lu.rhs, 4 * p + kk), lu.rhs);
                         }
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) mprev[kk] = m[kk];
                         if (p + 1 < NB) __syncthreads();
                     }
                     // The multipliers cover the rows above the pivot as well (the FMAs run on all 64 lanes anyway), so what is
