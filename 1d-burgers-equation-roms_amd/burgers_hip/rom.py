@@ -591,11 +591,22 @@ class AnnEvaluator:
                 run(); run()
             torch.cuda.current_stream(device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                run()
+            import gc
+            was_enabled = gc.isenabled()
+            gc.disable()           # a collection DURING capture may destroy an older evaluator's graph: the runtime aborts
+            try:
+                with torch.cuda.graph(g):
+                    run()
+            finally:
+                if was_enabled:
+                    gc.enable()
             self._graph = g
         except Exception:                                      # capture is an optimisation only
             self._graph = None
+
+    def release(self):
+        """Drop the captured graph now (outside any capture) instead of whenever the collector gets to it."""
+        self._graph = None
 
     def eval(self, q):
         """N(q) into qs_out and (dN/dq)^T into jt_out for the batch q (B, n), float64 in and out."""
@@ -678,6 +689,8 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
         iters[:, nt] = st.k
         hist[:, nt + 1] = U0
     flags |= st.flags
+    torch.cuda.current_stream(c.device).synchronize()
+    ann.release()
     return FomResult(hist, iters, flags)
 
 
