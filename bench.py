@@ -587,6 +587,20 @@ def allgather_svd_ms(w, res, dist_mod, backend):
 
 
 def run_rank(args):
+    # Exactly ONE line may reach stdout, and libraries below us write there too (gloo announces its connections on fd 1):
+    # everything printed while the rank runs goes to stderr, the JSON line alone to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return _run_rank(args, real_stdout)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+
+
+def _run_rank(args, real_stdout):
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -663,7 +677,7 @@ def run_rank(args):
         if gather is not None:
             line["allgather_svd"] = gather
             line["allgather_svd_ms"] = gather["allgather_svd_ms"]
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -17,8 +17,8 @@ KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 def _run(cmd, env=None, timeout=900):
     out = subprocess.run(cmd, capture_output=True, text=True, env=env or dict(os.environ), timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, out.stdout
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout          # ONE line on stdout, nothing else
     d = json.loads(lines[0])
     for k in KEYS:
         assert k in d, k
