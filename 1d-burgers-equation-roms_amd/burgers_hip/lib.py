@@ -77,6 +77,7 @@ _SIGNATURES = {
                                   ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
     "bg_rom_lift": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                    c_int_p, c_double_p, ctypes.c_void_p]),
+    "bg_quad_features": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_double_p, ctypes.c_void_p]),
     "bg_rom_frag_elems": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int]),
     "bg_rom_frag_pad": (ctypes.c_int, [ctypes.c_int]),
     "bg_quad_tangent": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,

@@ -429,8 +429,16 @@ def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0,
     # H3[i, a, b] = H[i, pair(a, b)] * (1 + delta_ab):  tangent = Phi + H3 . q   (:1120-1123)
     H3 = (Hd[:, idx] * fac).reshape(c.N * n, n).contiguous()
 
-    def decode(q):                                           # Phi q + H Q(q)        (:1116-1118)
-        return q @ PhiT + (q[:, I] * q[:, J]) @ HT
+    # decode u = Phi q + H Q(q) (:1116-1118) as ONE GEMM [q | Q(q)] . [Phi^T; H^T]; the left operand comes from bg_quad_features
+    WT = torch.cat([PhiT, HT], 0).contiguous()               # (n + k, N)
+    I32, J32 = I.to(torch.int32).contiguous(), J.to(torch.int32).contiguous()
+    feat = torch.empty((c.B, n + kk), dtype=torch.float64, device=c.device)
+
+    def decode(q):
+        with torch.cuda.device(c.device):
+            _lib.check(c.L.bg_quad_features(c.B, n, _lib.ptr(q), _lib.ptr(I32), _lib.ptr(J32), _lib.ptr(feat), c.stream()),
+                       "bg_quad_features")
+        return feat @ WT
 
     hist, iters, flags = _alloc_hist(c, nsteps)
     Ar, br, _, G = _workspace(c, n)
@@ -451,9 +459,10 @@ def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0,
         st.begin_step()
         while True:
             if Wf is not None:                               # fused HIP tangent -> fragment-major W -> MFMA reduce
-                qpad[:, :n] = q
+                if NP != n:
+                    qpad[:, :n] = q                          # (n = 40 needs no padding: q itself is the operand)
                 with torch.cuda.device(c.device):
-                    _lib.check(c.L.bg_quad_tangent(c.N, c.B, n, _lib.ptr(Phid), _lib.ptr(H3p), _lib.ptr(qpad),
+                    _lib.check(c.L.bg_quad_tangent(c.N, c.B, n, _lib.ptr(Phid), _lib.ptr(H3p), _lib.ptr(qpad if NP != n else q),
                                                    _lib.ptr(st.active), _lib.ptr(Wf), c.stream()), "bg_quad_tangent")
                     _lib.check(c.L.bg_rom_reduce_frag(c.N, c.B, n, proj, _lib.ptr(c.X), _lib.ptr(Wf), _lib.ptr(u),
                                                       _lib.ptr(G), _lib.ptr(c.hfs), _lib.ptr(c.mu1), c.dt, c.E, c.mesh_opt,

@@ -586,6 +586,24 @@ __global__ __launch_bounds__(256) void quad_tangent_kernel(const double* __restr
 }
 
 // ------------------------------------------------------------------------------------
+// quad_features_kernel: the left operand of the quadratic-manifold decode u = Phi q + H Q(q) (:1116-1118) as ONE matrix,
+// feat[b] = [q[b] | Q(q[b])] with Q = the unique products q_i q_j, j >= i, in get_sym's order (:263-273), so that the
+// decode is one GEMM against [Phi^T; H^T] instead of two gathers, a product, two GEMMs and an add.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quad_features_kernel(const double* __restrict__ q, const int32_t* __restrict__ pi,
+                                                            const int32_t* __restrict__ pj, double* __restrict__ feat, int B,
+                                                            int n, int k)
+{
+    const int w = n + k;
+    const long long total = (long long)B * w;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int b = (int)(e / w), c = (int)(e % w);
+        const double* qb = q + (size_t)b * n;
+        feat[e] = (c < n) ? qb[c] : qb[pi[c - n]] * qb[pj[c - n]];
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // bg_lu_solve: x = solve(A, sign * b), partial pivoting, one wavefront per system.
 //   lane i holds row i of [A | b]; rows are never moved: the pivot of step k is the
 //   not-yet-used lane with the largest |a[k]| (LAPACK gesv's choice up to ties in the
@@ -849,6 +867,18 @@ int bg_quad_tangent(int N, int B, int n, const double* Phi, const double* H3, co
         default: return BG_ERR_UNSUPPORTED_R;
     }
 #undef BG_QT
+    return check_launch();
+}
+
+int bg_quad_features(int B, int n, const double* q, const int32_t* pair_i, const int32_t* pair_j, double* feat, void* stream)
+{
+    if (B < 0 || n < 1) return BG_ERR_BAD_ARG;
+    if (B == 0) return BG_OK;
+    if (!q || !pair_i || !pair_j || !feat) return BG_ERR_BAD_ARG;
+    const int k = n * (n + 1) / 2;
+    const long long total = (long long)B * (n + k);
+    const int grid = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    hipLaunchKernelGGL(quad_features_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, q, pair_i, pair_j, feat, B, n, k);
     return check_launch();
 }
 

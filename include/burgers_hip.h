@@ -246,6 +246,12 @@ int bg_fd_run(int N, int B, int nsteps, const double *x, const double *u0, const
  *   bg_quad_tangent:        Wfrag[b] = Phi + H3 . q[b]   for every active sample
  *   bg_rom_reduce_frag:     bg_rom_reduce with W given in that layout (stride = bg_rom_frag_elems)
  * --------------------------------------------------------------------------------- */
+/* bg_quad_features -- feat[b] = [q[b] | Q(q[b])], Q = the n(n+1)/2 unique products q_i q_j (j >= i) in the order of
+ *   get_sym (FEM/fem_burgers.py:263-273): the left operand of the decode u = Phi q + H Q(q) (:1116-1118) as one matrix, so
+ *   that the decode is ONE GEMM against [Phi^T; H^T].  q [B][n]; pair_i, pair_j [n(n+1)/2] int32 (row-major upper
+ *   triangle); feat [B][n + n(n+1)/2]. */
+int bg_quad_features(int B, int n, const double *q, const int32_t *pair_i, const int32_t *pair_j, double *feat,
+                     void *stream);
 long long bg_rom_frag_elems(int N, int r);
 int bg_rom_frag_pad(int r);
 int bg_quad_tangent(int N, int B, int n, const double *Phi, const double *H3, const double *q,
