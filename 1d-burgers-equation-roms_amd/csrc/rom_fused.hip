@@ -1,17 +1,18 @@
 // rom_fused.hip -- the whole POD-PROM time loop of one sample on one compute unit, and its C-ABI entry point.
 //
 // Replaces FEMBurgers.pod_prom_burgers (reference FEM/fem_burgers.py:709-785) for a batch of samples: one 256-thread
-// workgroup owns a sample for ALL time steps and ALL Picard iterations.  The basis fragments stay in registers, u, g,
-// the per-sample load constants, the reduced system and q stay in LDS; HBM sees the initial state once and one
-// N-row history write per time step.  Per iteration, with no kernel boundary and no host in between:
+// workgroup owns a sample for ALL time steps and ALL Picard iterations.  The basis fragments stay in registers (their halo
+// rows in LDS), u, g, the per-sample load constants, the reduced system and q stay in LDS; HBM sees the initial state
+// once and one N-row history write per time step.  Per iteration, with no kernel boundary and no host in between:
 //     assembly (2 rows per thread)  ->  fp64 MFMA projection (v_mfma_f64_4x4x4_4b, as rom_reduce4_kernel)
 //     ->  r x r solve by all four waves (below)  ->  q = Phi^T u + dq, error, stopping test  ->  lift u = Phi q.
 //
 // The reduced solve.  np.linalg.solve (:767) is LU with partial pivoting.  On these systems (cond(Ar) < 10 on the
 // reference's bases) LAPACK never leaves the diagonal, so the kernel eliminates WITHOUT a pivot search and watches
 // the multipliers: as long as every |l_ik| <= 1 the diagonal was the column maximum at every step, i.e. the
-// operations are the ones partial pivoting performs.  If one multiplier exceeds 1 (or a pivot is 0 / not finite)
-// the system is solved again by the pivoted single-wave routine lu_pivoted_wave -- same semantics as bg_lu_solve.
+// operations are the ones partial pivoting performs.  If one multiplier exceeds 1 (or a pivot is 0) the sample is
+// marked and redone from u0 by the repair kernel (PIV = true) launched behind the fast one: same code with the
+// partial-pivoting single-wave routine of bg_lu_solve (lu_pivoted_wave) as its solve.
 // The unpivoted elimination is spread over the four waves: lane = row, wave w owns the 4-column blocks
 // b = w, w+4, w+8 (the right-hand side rides with wave 3); the owner of panel p factors it in its own registers
 // (no communication inside a panel), publishes the four multiplier vectors through LDS, and every wave applies them
@@ -27,8 +28,10 @@
 #include "rom_device.hpp"
 
 // Phase ablation for tools/time_fused.py (never defined in the product build): BG_FUSED_ABLATE is a bit mask of phases to
-// compile out (1 MFMA passes, 2 elimination, 8 lift, 16 assembly, 32 MFMA epilogue, 64 per-step operand formation); the iteration count is then
-// fixed at 5 per time step and the pivoted fallback is disabled, so that the garbage values cannot change the control flow.
+// compile out (1 MFMA passes, 2 elimination, 8 lift, 16 assembly, 32 MFMA epilogue, 64 per-step operand formation); the
+// iteration count is then fixed at 5 per time step, the multiplier guard is ignored and the repair kernel is not launched,
+// so that the garbage values cannot change the control flow.  Such builds also stamp s_memtime / s_memrealtime per sample
+// into iters[b][0..1] (the in-kernel clock, printed by tools/time_fused.py).
 #ifndef BG_FUSED_ABLATE
 #define BG_FUSED_ABLATE -1
 #endif
