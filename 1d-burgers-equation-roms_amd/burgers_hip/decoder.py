@@ -36,9 +36,11 @@ def predict_on_grid(mu1, mu2, Nt, U_modes, model, mean, std, dtype=torch.float32
     model = model.to(device=device, dtype=dtype)
     Um = torch.as_tensor(np.asarray(U_modes), device=device)
     with torch.no_grad():
-        Q = model(Zs.to(dtype))                                   # (B*Nt, n)
+        Q = model(Zs.to(dtype)).reshape(B, Nt, -1)                 # (B, Nt, n)
+        # Uhat[b] = U_modes @ Q[b]^T as ONE batched product that lands directly in the (B, N, Nt) result layout
+        # (a (N, B*Nt) product followed by permute + contiguous moves the 8-byte result twice more)
         if dtype == torch.float32:
-            U = Um.to(torch.float64) @ Q.to(torch.float64).t()     # reference: float64 modes @ float32 output
+            U = torch.matmul(Um.to(torch.float64), Q.to(torch.float64).transpose(1, 2))     # reference: float64 modes @ float32 output
         else:
-            U = (Um.to(dtype) @ Q.t()).to(torch.float64)           # bf16 tier: low-precision GEMM, fp32 accumulate
-    return U.reshape(Um.shape[0], B, Nt).permute(1, 0, 2).contiguous()
+            U = torch.matmul(Um.to(dtype), Q.transpose(1, 2)).to(torch.float64)             # bf16 tier: low-precision GEMM, fp32 accumulate
+    return U
