@@ -65,12 +65,13 @@ def check_mesh(X):
 
 
 def fom_run(X, u0, mu1, mu2, dt, nsteps, E=0.0, tol=1e-6, max_it=20, supg=True, device=None,
-            out=None, validate_mesh=True, options=None):
+            out=None, validate_mesh=True, options=None, trace=False):
     """Run B samples through ``nsteps`` implicit-Euler steps on the current HIP stream.
 
     X (N,), u0 (N,) or (B, N), mu1/mu2 scalar or (B,).  Returns a :class:`FomResult` of
     device tensors; nothing is synchronised.  ``out``: a FomResult whose tensors are reused as the
     destination (shape, dtype, device and contiguity are checked: the kernel writes through raw pointers).
+    ``trace``: also return ``res.errs`` (B, nsteps, max_it), the error of every Picard iteration (NaN where none ran).
     """
     L = _lib.load()
     device = _lib.require_device(device)
@@ -94,12 +95,24 @@ def fom_run(X, u0, mu1, mu2, dt, nsteps, E=0.0, tol=1e-6, max_it=20, supg=True, 
             if tuple(t.shape) != shape or t.dtype != dt_ or t.device != device or not t.is_contiguous():
                 raise ValueError(f"out.{name} must be a contiguous {dt_} tensor of shape {shape} on {device} "
                                  f"(got {tuple(t.shape)}, {t.dtype}, {t.device})")
-    with torch.cuda.device(device):
-        rc = L.bg_fom_run(N, B, int(nsteps), _lib.ptr(Xd), _lib.ptr(u0d), _lib.ptr(mu1d), _lib.ptr(mu2d),
-                          float(dt), float(E), float(tol), int(max_it), int(options),
-                          _lib.ptr(hist), _lib.ptr(iters), _lib.ptr(flags), _lib.stream_ptr(device))
+    errs = None
+    if trace:                          # error of every iteration (what the reference prints, :664); N <= 1536
+        errs = torch.full((B, int(nsteps), int(max_it)), float("nan"), dtype=torch.float64, device=device)
+        with torch.cuda.device(device):
+            rc = L.bg_fom_run_traced(N, B, int(nsteps), _lib.ptr(Xd), _lib.ptr(u0d), _lib.ptr(mu1d), _lib.ptr(mu2d),
+                                     float(dt), float(E), float(tol), int(max_it), int(options), _lib.ptr(hist),
+                                     _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(errs), _lib.stream_ptr(device))
+        if rc == _lib.BG_ERR_UNSUPPORTED_N:
+            trace, errs = False, None  # workgroup-per-sample sizes: no traced kernel
+    if not trace:
+        with torch.cuda.device(device):
+            rc = L.bg_fom_run(N, B, int(nsteps), _lib.ptr(Xd), _lib.ptr(u0d), _lib.ptr(mu1d), _lib.ptr(mu2d),
+                              float(dt), float(E), float(tol), int(max_it), int(options),
+                              _lib.ptr(hist), _lib.ptr(iters), _lib.ptr(flags), _lib.stream_ptr(device))
     _lib.check(rc, "bg_fom_run")
-    return FomResult(hist, iters, flags)
+    res = FomResult(hist, iters, flags)
+    res.errs = errs
+    return res
 
 
 def fom_assemble(X, uk, un, mu1, mu2, dt, E=0.0, supg=True, device=None):

@@ -42,6 +42,10 @@ _SIGNATURES = {
                                   c_double_p, c_double_p, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, ctypes.c_int, ctypes.c_int, c_double_p, c_int_p,
                                   c_int_p, ctypes.c_void_p]),
+    "bg_fom_run_traced": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                         c_double_p, c_double_p, ctypes.c_double, ctypes.c_double,
+                                         ctypes.c_double, ctypes.c_int, ctypes.c_int, c_double_p, c_int_p,
+                                         c_int_p, c_double_p, ctypes.c_void_p]),
     "bg_fom_assemble": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                        c_double_p, c_double_p, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p,

@@ -31,6 +31,7 @@ struct FomArgs {
     int32_t* flags;
     double dt, E, tol2;
     int N, B, nsteps, max_it, supg;
+    double* errs;        // [B][nsteps][max_it], TRACE instantiations only: the error of every Picard iteration
 };
 
 constexpr int WAVES_PER_WG = 4;
@@ -52,7 +53,9 @@ __device__ __forceinline__ void store_rows(double* __restrict__ dst, int N, int 
         if (full || row0 + j < N) dst[row0 + j] = u[j];
 }
 
-template <int R, bool FULL, bool UNI = true>
+// TRACE: also store error_U = ||dU|| / ||U1|| of every iteration (what the reference prints at :664); a separate
+// instantiation, so that the hot kernel carries no trace of it.
+template <int R, bool FULL, bool UNI = true, bool TRACE = false>
 __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void fom_fused_kernel(FomArgs a)
 {
     const int lane = lane_id();
@@ -96,6 +99,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 1) void fom_fused_kernel(FomArgs
                 nu = __builtin_fma(u[j], u[j], nu);
             }
             wave_sum2(nd, nu, nd, nu);
+            if constexpr (TRACE) {
+                if (lane == 0) a.errs[((size_t)s * a.nsteps + step) * a.max_it + k] = sqrt(nd) / sqrt(nu);
+            }
             ++k;
             // reference: error = ||dU|| / ||U1||; continue while error > tol and k < cap.
             // NaN compares false and ends the loop, as in the reference.
@@ -389,7 +395,7 @@ int bg_fom_run(int N, int B, int nsteps, const double* x, const double* u0, cons
     if (B == 0) return BG_OK;
     if (!x || !u0 || !mu1 || !mu2 || !hist || !flags || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
     FomArgs a;
-    a.x = x; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
+    a.x = x; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags; a.errs = nullptr;
     a.dt = dt; a.E = E; a.tol2 = tol * tol;
     a.N = N; a.B = B; a.nsteps = nsteps; a.max_it = max_it; a.supg = supg & BG_OPT_SUPG;
     const bool nonuniform = (supg & BG_OPT_NONUNIFORM) != 0;
@@ -412,6 +418,31 @@ int bg_fom_run(int N, int B, int nsteps, const double* x, const double* u0, cons
             hipLaunchKernelGGL((fom_fused_kernel<R, true>), grid, block, 0, st, a);
         else
             hipLaunchKernelGGL((fom_fused_kernel<R, false>), grid, block, 0, st, a);
+        return check_launch();
+    });
+}
+
+int bg_fom_run_traced(int N, int B, int nsteps, const double* x, const double* u0, const double* mu1, const double* mu2,
+                      double dt, double E, double tol, int max_it, int supg, double* hist, int32_t* iters, int32_t* flags,
+                      double* errs, void* stream)
+{
+    if (N < 2 || B < 0 || nsteps < 0 || max_it < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
+    if (N > kWaveMaxN) return BG_ERR_UNSUPPORTED_N;         // the wave-per-sample kernels only
+    if (B == 0) return BG_OK;
+    if (!x || !u0 || !mu1 || !mu2 || !hist || !flags || !errs || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
+    FomArgs a;
+    a.x = x; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags; a.errs = errs;
+    a.dt = dt; a.E = E; a.tol2 = tol * tol;
+    a.N = N; a.B = B; a.nsteps = nsteps; a.max_it = max_it; a.supg = supg & BG_OPT_SUPG;
+    const bool nonuniform = (supg & BG_OPT_NONUNIFORM) != 0;
+    const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_r(N, [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        if (nonuniform)
+            hipLaunchKernelGGL((fom_fused_kernel<R, false, false, true>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((fom_fused_kernel<R, false, true, true>), grid, block, 0, st, a);
         return check_launch();
     });
 }

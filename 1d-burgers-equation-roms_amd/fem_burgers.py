@@ -67,9 +67,19 @@ class FEMBurgers:
         self.last_flags = res.flags.cpu().numpy()
         U = _lib.to_host(snaps)
         if self.verbose:
+            errs = getattr(res, "errs", None)
+            errs = None if errs is None else errs.cpu().numpy()
+            At = getattr(self, "_last_At", None)
             for b in range(U.shape[0]):
                 for n, k in enumerate(self.last_iters[b]):
-                    print(f"Time Step: {n}. Iterations: {int(k)}")
+                    if errs is not None and At is not None:
+                        # the reference's own console lines (:659, :664): the error shown at iteration k is the one
+                        # of iteration k - 1 (1 before the first)
+                        print(f"Time Step: {n}. Time: {n * At}")
+                        for j in range(int(k)):
+                            print(f"Iteration: {j}, Error: {1 if j == 0 else float(errs[b, n, j - 1])}")
+                    else:
+                        print(f"Time Step: {n}. Iterations: {int(k)}")
         if not batched:
             self.last_iters = self.last_iters[0]
             self.last_flags = int(self.last_flags[0])
@@ -80,8 +90,9 @@ class FEMBurgers:
     def fom_burgers(self, At, nTimeSteps, u0, mu1, E, mu2):
         """Implicit-Euler / Picard FOM (reference :646-707).  Returns ``(N, nTimeSteps+1)``."""
         batched = self._batched(mu1, mu2, u0)
+        self._last_At = At
         res = _fom.fom_run(self.X, np.asarray(u0, dtype=np.float64), mu1, mu2, At, int(nTimeSteps), E=E,
-                           tol=1e-6, max_it=20, supg=True)
+                           tol=1e-6, max_it=20, supg=True, trace=bool(self.verbose))
         return self._finish(res, batched)
 
     # --------------------------------------------------------------- POD-Galerkin / LSPG

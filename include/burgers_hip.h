@@ -95,6 +95,14 @@ int bg_fom_run(int N, int B, int nsteps, const double *x, const double *u0, cons
                const double *mu2, double dt, double E, double tol, int max_it, int supg,
                double *hist, int32_t *iters, int32_t *flags, void *stream);
 
+/* bg_fom_run_traced -- bg_fom_run that also stores the error of every Picard iteration, the value the reference prints
+ *   per iteration (`print(f"Iteration: {k}, Error: {error_U}")`, FEM/fem_burgers.py:664; error_U = ||dU|| / ||U1|| of :698).
+ *   errs [B][nsteps][max_it]: errs[b][t][k] = error after iteration k of step t (entries k >= iters[b][t] untouched).
+ *   Same results as bg_fom_run; a separate kernel instantiation, N <= 1536 (BG_ERR_UNSUPPORTED_N beyond). */
+int bg_fom_run_traced(int N, int B, int nsteps, const double *x, const double *u0, const double *mu1,
+                      const double *mu2, double dt, double E, double tol, int max_it, int supg,
+                      double *hist, int32_t *iters, int32_t *flags, double *errs, void *stream);
+
 /* ---------------------------------------------------------------------------------
  * bg_fom_assemble -- one Picard assembly, for inspection and tests
  *   reference: FEM/fem_burgers.py:666-689 (C, S, F, A with Dirichlet row, b, R).

@@ -232,8 +232,9 @@ def system_tridiag(M3, K3, C3, At, E):
 # FOM                                               (fem_burgers.py:646-707)
 # --------------------------------------------------------------------------
 def fom_burgers(X, At, nTimeSteps, u0, mu1, E, mu2, tol=1e-6, max_it=20,
-                return_iters=False):
-    """Implicit-Euler / Picard FOM; returns ``U (N, nTimeSteps+1)``."""
+                return_iters=False, return_errs=False):
+    """Implicit-Euler / Picard FOM; returns ``U (N, nTimeSteps+1)`` (and the iteration counts; and ``errs
+    (nTimeSteps, max_it)``, error_U of every iteration as the reference prints it at :664, NaN where none ran)."""
     X = np.asarray(X, dtype=np.float64)
     n = len(X)
     U = np.zeros((n, nTimeSteps + 1))
@@ -242,6 +243,7 @@ def fom_burgers(X, At, nTimeSteps, u0, mu1, E, mu2, tol=1e-6, max_it=20,
     K3 = diffusion_tridiag(X)
     F = forcing_vector(X, mu2)          # constant; the reference recomputes it (:673)
     iters = np.zeros(nTimeSteps, dtype=np.int32)
+    errs = np.full((nTimeSteps, max_it), np.nan)
     for nstep in range(nTimeSteps):
         Un = U[:, nstep]
         U0 = Un
@@ -259,10 +261,13 @@ def fom_burgers(X, At, nTimeSteps, u0, mu1, E, mu2, tol=1e-6, max_it=20,
             dU = tridiag_solve(lo, di, up, -R)
             U1 = U0 + dU
             err = np.linalg.norm(dU) / np.linalg.norm(U1)
+            errs[nstep, k] = err
             U0 = U1
             k += 1
         iters[nstep] = k
         U[:, nstep + 1] = U1
+    if return_errs:
+        return U, iters, errs
     return (U, iters) if return_iters else U
 
 

@@ -486,3 +486,34 @@ def test_fd_jacobian_option(hip):
     for b in range(3):
         Uo, ito = br.fd_newton(0.0, 100.0, 64, 0.1, 4, np.ones(64), mu1[b], mu2[b], return_iters=True, use_fd_jacobian=True)
         assert rel_l2(Ub[b], Uo) < 1e-9 and np.array_equal(fd.last_iters[b], ito)      # eps = 1e-8 differences: 1e-9, not 1e-10
+
+
+def test_traced_run_and_reference_console_lines(hip, capsys):
+    """bg_fom_run_traced: same history and iteration counts as bg_fom_run, plus error_U of every iteration (:698) equal to
+    the oracle's; with ``verbose`` the facade prints the reference's own lines (`Time Step: n. Time: t` :659,
+    `Iteration: k, Error: e` :664, the error shown at iteration k being the previous one, 1 before the first)."""
+    from burgers_hip import fom
+    from fem_burgers import FEMBurgers
+    N, nT, dt = 256, 6, 0.05
+    X, T = mesh(N)
+    mu1, mu2 = np.array([4.4, 5.3]), np.array([0.018, 0.027])
+    a = fom.fom_run(X, np.ones(N), mu1, mu2, dt, nT)
+    t = fom.fom_run(X, np.ones(N), mu1, mu2, dt, nT, trace=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a.hist, t.hist) and torch.equal(a.iters, t.iters) and torch.equal(a.flags, t.flags)
+    errs = t.errs.cpu().numpy()
+    for b in range(2):
+        U, it, eo = br.fom_burgers(X, dt, nT, np.ones(N), mu1[b], 0.0, mu2[b], return_iters=True, return_errs=True)
+        ran = ~np.isnan(eo)
+        assert np.array_equal(np.isnan(errs[b]), ~ran)
+        assert np.allclose(errs[b][ran], eo[ran], rtol=1e-6, atol=0.0)          # ratios of norms of converging updates
+    fem = FEMBurgers(X, T)
+    fem.verbose = True
+    capsys.readouterr()
+    fem.fom_burgers(dt, nT, np.ones(N), 4.4, 0.0, 0.018)
+    lines = capsys.readouterr().out.splitlines()
+    it0 = a.iters[0].cpu().numpy()
+    assert len(lines) == nT + int(it0.sum())
+    assert lines[0] == f"Time Step: 0. Time: {0 * dt}" and lines[1] == "Iteration: 0, Error: 1"
+    assert lines[2].startswith("Iteration: 1, Error: ") and abs(float(lines[2].split("Error: ")[1]) - errs[0, 0, 0]) < 1e-12
+    assert lines[1 + int(it0[0])] == f"Time Step: 1. Time: {1 * dt}"
