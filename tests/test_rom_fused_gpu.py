@@ -164,3 +164,28 @@ def test_fused_tiny_and_odd_shapes(hip, N, r, B):
                 tol = 1e-10 if (ito < 20).all() else 1e-6
                 assert rel_l2(res.hist[b].cpu().numpy().T, U) < tol, (proj, b)
                 assert np.array_equal(res.iters[b].cpu().numpy(), ito), (proj, b)
+
+
+def test_fused_full_size_properties(hip):
+    """BASELINE configs[2] at full batch (4096 samples, r = 40) through bg_rom_run, size-independent properties: the result
+    does not depend on where a sample sits in the batch (permutation, bit-for-bit), a run restarted from a stored column
+    continues bit-for-bit (the lifted state and the stored history row are the same doubles), column 0 is u0, nothing is
+    flagged.  (The Dirichlet value is NOT a property of the PROM: u = Phi q imposes it only through the projection.)"""
+    from burgers_hip import rom
+    g = load_golden("committed_pod_r40.npz")
+    rng = np.random.default_rng(20251121)
+    X, _ = mesh(512)
+    B, nT = 4096, 8
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    perm = rng.permutation(B)
+    for proj in ("Galerkin", "LSPG"):
+        a = rom.pod_prom_run(X, np.ones(512), mu1, mu2, 0.05, nT, g["Phi"], projection=proj)
+        p = rom.pod_prom_run(X, np.ones(512), mu1[perm], mu2[perm], 0.05, nT, g["Phi"], projection=proj)
+        permd = torch.as_tensor(perm, device="cuda")
+        assert torch.equal(a.hist[permd], p.hist) and torch.equal(a.iters[permd], p.iters) and torch.equal(a.flags[permd], p.flags)
+        first = rom.pod_prom_run(X, np.ones(512), mu1, mu2, 0.05, 4, g["Phi"], projection=proj)
+        rest = rom.pod_prom_run(X, first.hist[:, 4].contiguous(), mu1, mu2, 0.05, nT - 4, g["Phi"], projection=proj)
+        assert torch.equal(first.hist, a.hist[:, :5]) and torch.equal(rest.hist, a.hist[:, 4:])
+        assert torch.equal(torch.cat([first.iters, rest.iters], 1), a.iters)
+        assert torch.equal(a.hist[:, 0], torch.ones((B, 512), dtype=torch.float64, device="cuda"))
+        assert int(a.flags.sum().item()) == 0 and int(a.info.sum().item()) == 0
