@@ -25,23 +25,12 @@
 
 #include "../../include/burgers_hip.h"
 #include "abi_common.hpp"
-#include "rom_device.hpp"
-
-// Phase ablation for tools/time_fused.py (never defined in the product build): BG_FUSED_ABLATE is a bit mask of phases to
-// compile out (1 MFMA passes, 2 elimination, 8 lift, 16 assembly, 32 MFMA epilogue, 64 per-step operand formation); the
-// iteration count is then fixed at 5 per time step, the multiplier guard is ignored and the repair kernel is not launched,
-// so that the garbage values cannot change the control flow.  Such builds also stamp s_memtime / s_memrealtime per sample
-// into iters[b][0..1] (the in-kernel clock, printed by tools/time_fused.py).
-#ifndef BG_FUSED_ABLATE
-#define BG_FUSED_ABLATE -1
-#endif
+#include "rom_fused_device.hpp"
 
 namespace {
 
 using namespace bg;
-constexpr int kAblate = BG_FUSED_ABLATE;
-constexpr bool kTiming = kAblate >= 0;
-constexpr bool skip(int bit) { return kTiming && (kAblate & bit) != 0; }
+using namespace bg::fused;
 
 struct RomRunArgs {
     const double* x;        // [N]
@@ -57,175 +46,12 @@ struct RomRunArgs {
     int N, B, r, nsteps, max_it, supg, nonuniform, force_pivoted;
 };
 
-// ---- one MFMA pass over this wave's rows: pairs (ca, cb) with ca in [CA0, CA1) ---------------------------------
-// Same operand layout, accumulation order and block-partial summation as rom_reduce4_kernel (rom.hip), so the
-// reduced system has the bits of the batched path.  frag[c][s] = Phi[rowbase + s][4 c + t]; the two halo rows
-// Phi[rowbase - 1], Phi[rowbase + S] of every column block sit in LDS (s_halo[0 / 1][c][tid], one private slot per
-// thread: conflict-free 8-byte reads) and are fetched when the first / last row step needs them -- 40 VGPRs fewer
-// live across the whole kernel.  LAST: this pass also carries the Phi^T u accumulators of the LSPG form.
-template <int S, int NB, bool GAL, int CA0, int CA1, bool LAST, int RW>
-__device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const double (*__restrict__ s_halo)[NB][256],
-                                          const double (*__restrict__ s_coef)[4], const double* __restrict__ s_u,
-                                          int rowbase, int t, int w, int lane, int tid,
-                                          double (*__restrict__ s_red)[RW][RW + 4], double (*__restrict__ s_wtu)[RW])
-{
-    constexpr int NROW = GAL ? (CA1 - CA0) * (NB + 1) : (CA1 - CA0) * (2 * NB - CA0 - CA1 + 1) / 2 + (CA1 - CA0);
-    constexpr int NACC = NROW + ((!GAL && LAST) ? NB : 0);
-    double acc[NACC];
-#pragma unroll
-    for (int p = 0; p < NACC; ++p) acc[p] = 0.0;
-    // B operands of row step s: Y = (A Phi) rows, X = extra block [R, u, 0, 0]
-    auto operands = [&](int s, double (&Y)[NB], double& X) {
-        const int i = rowbase + s;
-        const double lo = s_coef[i][0], di = s_coef[i][1], up = s_coef[i][2], R = s_coef[i][3];
-        const double ui = s_u[i + 2];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            const double below = (s == 0) ? s_halo[0][c][tid] : frag[c][s == 0 ? 0 : s - 1];
-            const double above = (s == S - 1) ? s_halo[1][c][tid] : frag[c][s == S - 1 ? s : s + 1];
-            double y = lo * below;
-            y = __builtin_fma(di, frag[c][s], y);
-            y = __builtin_fma(up, above, y);
-            Y[c] = y;
-        }
-        X = (t == 0) ? R : ((t == 1) ? ui : 0.0);
-    };
-    // No software pipelining here: measured (tools/mfma_valu_bench.hip) the fp64 4x4x4 MFMA does not overlap with vector
-    // ALU work of the same wave -- 110 MFMAs take 882 ns alone and 882 + 2.25 ns per interleaved v_fma_f64 -- so the
-    // phase costs the MFMAs plus every other instruction; interleaving only adds hazard s_nops (498 against 103).
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        double Y[NB], X;
-        operands(skip(64) ? 0 : s, Y, X);        // (64: timing only)
-        int p = 0;
-        if constexpr (GAL) {
-#pragma unroll
-            for (int ca = CA0; ca < CA1; ++ca) {
-#pragma unroll
-                for (int cb = 0; cb < NB; ++cb, ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], Y[cb], acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], X, acc[p], 0, 0, 0);
-                ++p;
-            }
-        } else {
-#pragma unroll
-            for (int ca = CA0; ca < CA1; ++ca) {
-#pragma unroll
-                for (int cb = ca; cb < NB; ++cb, ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(Y[ca], Y[cb], acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(Y[ca], X, acc[p], 0, 0, 0);
-                ++p;
-            }
-            if constexpr (LAST) {
-#pragma unroll
-                for (int ca = 0; ca < NB; ++ca, ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], X, acc[p], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);       // nothing moves across a step: bounded register pressure
-    }
-    // sum the four block partials of every pair (lanes differing in bits 2..3), park them per wave in LDS
-    const int oi = lane >> 4, oj = lane & 3;
-    const bool writer = ((lane >> 2) & 3) == 3;
-    int p = 0;
-    if constexpr (skip(32)) {                    // timing only: keep the MFMAs alive, drop the block sums and stores
-        double v = 0.0;
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) v += acc[q];
-        if (writer) s_red[w][oi][oj] = v;
-        return;
-    }
-#pragma unroll
-    for (int ca = CA0; ca < CA1; ++ca) {
-#pragma unroll
-        for (int cb = (GAL ? 0 : ca); cb <= NB; ++cb, ++p) {
-            double v = acc[p];
-            v += dpp_mov<0x114>(v);          // row_shr:4
-            v += dpp_mov<0x118>(v);          // row_shr:8 -> lanes with blk == 3 hold the sum
-            if (writer) s_red[w][4 * ca + oi][4 * cb + oj] = v;
-        }
-    }
-    if constexpr (!GAL && LAST) {
-#pragma unroll
-        for (int ca = 0; ca < NB; ++ca, ++p) {
-            double v = acc[p];
-            v += dpp_mov<0x114>(v);
-            v += dpp_mov<0x118>(v);
-            if (writer && oj == 1) s_wtu[w][4 * ca + oi] = v;
-        }
-    }
-}
-
-// ---- cooperative unpivoted elimination (see the file header) ----------------------------------------------------
-template <int NB>
-struct LuRegs {
-    static constexpr int NSLOT = (NB + 3) / 4;
-    double col[NSLOT][4];     // slot s = column block w + 4 s
-    double rhs;               // wave 3 only
-};
-
-template <int NB>
-__device__ __forceinline__ void lu_apply_block(double (&c)[4], const double (&m)[4], int p)
-{
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {             // step-major: the eight readlanes of a step, then its four FMAs
-        double piv[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) piv[t] = readlane_f64(c[t], 4 * p + kk);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) c[t] = __builtin_fma(-m[kk], piv[t], c[t]);
-    }
-}
-
-// factor the panel held in c[0..3] (columns 4p .. 4p+3, pivots in lanes 4p .. 4p+3); multipliers -> sm[kk][lane]
-// gmax: running maximum of the sub-diagonal |multipliers| (the partial-pivoting guard); zero_piv: a pivot was exactly 0
-__device__ __forceinline__ void lu_factor_panel(double (&c)[4], int p, int lane, double (*__restrict__ sm)[64], double& gmax,
-                                                bool& zero_piv)
-{
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const int k = 4 * p + kk;
-        const double piv = readlane_f64(c[kk], k);
-        const double rp = rcp(piv);
-        const double m = (lane != k) ? c[kk] * rp : 0.0;          // rows ABOVE the pivot too (Gauss-Jordan, see the kernel)
-        gmax = fmax(gmax, (lane > k) ? fabs(m) : 0.0);            // branch-free: a short-circuit here costs 3.7 us per solve
-        zero_piv = zero_piv | (piv == 0.0);
-#pragma unroll
-        for (int jj = kk + 1; jj < 4; ++jj) c[jj] = __builtin_fma(-m, readlane_f64(c[jj], k), c[jj]);
-        sm[kk][lane] = m;
-    }
-}
-
-// The partial-pivoting solve of the repair kernel (PIV): one wave reloads the summed system from the per-wave partials and
-// runs the routine of bg_lu_solve.  It lives in a kernel of its own: as a cold branch (even out of line) inside the fast
-// kernel it cost 4.7 us per iteration through the register allocation around the call site.
-template <int NB, bool GAL>
-__device__ __forceinline__ void pivoted_solve(const double (*__restrict__ s_red)[4 * NB][4 * NB + 4],
-                                              double* __restrict__ s_x, int* __restrict__ s_info, int lane, int r)
-{
-    constexpr int RW = 4 * NB;
-    auto entry = [&](int i, int j) -> double {
-        int rr = i, cc = j;
-        if (!GAL && j < RW && (i >> 2) > (j >> 2)) { rr = j; cc = i; }
-        return (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
-    };
-    double row[RW + 1];
-#pragma unroll
-    for (int j = 0; j < RW; ++j) row[j] = (lane < r && j < r) ? entry(lane, j) : ((lane == j) ? 1.0 : 0.0);
-    row[RW] = (lane < r) ? -entry(lane, RW) : 0.0;
-    int info;
-    const double xs = lu_pivoted_wave<RW>(row, lane, info);
-    if (lane < RW) s_x[lane] = xs;
-    if (lane == 0) *s_info = info;
-}
-
 template <int S, int NB, int PROJ, bool PIV>
 __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
 {
     constexpr int NPAD = 64 * S;
     constexpr int RW = 4 * NB;                   // padded reduced dimension
     constexpr bool GAL = PROJ == BG_PROJ_GALERKIN;
-    constexpr int NSLOT = LuRegs<NB>::NSLOT;
     __shared__ double s_u[NPAD + 4];             // u at offset 2, zero halo on each side
     __shared__ double s_g[NPAD];                 // M u^n + dt F of the current time step
     __shared__ double s_h[NPAD];                 // hfs: h_e (f(gp1) + f(gp2)) per element
@@ -363,70 +189,9 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                     xout = (lane < RW) ? s_x[lane] : 0.0;
                     if (s_info != 0 && info_out == 0) info_out = s_info;
                 } else {
-                    LuRegs<NB> lu;
-#pragma unroll
-                    for (int s = 0; s < NSLOT; ++s) {
-                        const int b = w + 4 * s;
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt) {
-                            const int j = 4 * b + tt;
-                            double v = 0.0;
-                            if (b < NB && lane < RW) v = (lane >= r || j >= r) ? ((lane == j) ? 1.0 : 0.0) : entry(lane, j);
-                            lu.col[s][tt] = v;
-                        }
-                    }
-                    lu.rhs = (w == 3 && lane < r) ? -entry(lane, RW) : 0.0;           // solve(Ar, -br)
-                    double gmax = 0.0;
-                    bool zero_piv = false;
-                    if (w == 0) lu_factor_panel(lu.col[0], 0, lane, s_m[0], gmax, zero_piv);
-                    __syncthreads();
-                    double mprev[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int p = 0; p < (skip(2) ? 0 : NB); ++p) {
-                        double m[4];
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) m[kk] = s_m[p & 1][kk][lane];
-                        const int nxt = p + 1;
-                        const bool owner_next = nxt < NB && w == (nxt & 3);
-                        const bool owner_this = p > 0 && w == (p & 3);       // deferred panel p - 1 for its later blocks
-                        if (owner_next) {                                     // look-ahead: next panel first ...
-                            lu_apply_block<NB>(lu.col[nxt >> 2], m, p);
-                            lu_factor_panel(lu.col[nxt >> 2], nxt, lane, s_m[nxt & 1], gmax, zero_piv);
-                        }
-#pragma unroll
-                        for (int s = 0; s < NSLOT; ++s) {
-                            const int b = w + 4 * s;
-                            if (b > p && b < NB && b != nxt && !owner_next) {   // ... and its other blocks one panel later,
-                                if (owner_this) lu_apply_block<NB>(lu.col[s], mprev, p - 1);   // so that no wave carries
-                                lu_apply_block<NB>(lu.col[s], m, p);                           // factor + three updates
-                            }
-                        }
-                        if (w == 3) {
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) lu.rhs = __builtin_fma(-m[kk], readlane_f64(lu.rhs, 4 * p + kk), lu.rhs);
-                        }
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) mprev[kk] = m[kk];
-                        if (p + 1 < NB) __syncthreads();
-                    }
-                    // The multipliers cover the rows above the pivot as well (the FMAs run on all 64 lanes anyway), so what is
-                    // left is diagonal: x_k = y_k / d_k, no back substitution.  Publish d (owner of each column) and y (wave 3).
-#pragma unroll
-                    for (int s = 0; s < NSLOT; ++s) {
-                        const int b = w + 4 * s;
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt)
-                            if (b < NB && lane == 4 * b + tt) s_diag[lane] = lu.col[s][tt];
-                    }
-                    if (w == 3 && lane < RW) s_y[lane] = lu.rhs;
-                    {
-                        const unsigned long long anybad = __ballot(zero_piv | !(gmax <= 1.0));
-                        if (lane == 0) s_bad[w] = anybad != 0ull;
-                    }
-                    // ---- solution, every wave for itself (same values in all four) ---------------------------------------
-                    __syncthreads();
-                    if (!kTiming && (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0) aborted = true;      // workgroup-uniform
-                    xout = (lane < RW) ? s_y[lane] * rcp(s_diag[lane]) : 0.0;
+                    bool tripped;
+                    xout = coop_gj_solve<NB, GAL, !skip(2)>(s_red, s_m, s_diag, s_y, s_bad, w, lane, r, tripped);
+                    if (!kTiming && tripped) aborted = true;
                 }
                 // ---- q = Phi^T u_k + dq, err = |dq| / |q|  (:770-776) ---------------------------------------------
                 double wtu = 0.0;
