@@ -662,14 +662,91 @@ class _ClosureTangent:
         return self.gemm()
 
 
+def _ann_fused_plan(model, n, nbar, N, dtype, device):
+    """The closure as bg_ann_rom_run wants it, or None when the device-side loop does not apply (not a plain fp32
+    MLP the evaluator recognises, or beyond bg_ann_rom_limits)."""
+    import ctypes
+    import torch.nn as nn
+    if dtype != torch.float32 or N > 512:
+        return None
+    ann = AnnEvaluator(model, n, dtype)
+    if ann.layers is None:
+        return None
+    L = _lib.load()
+    lim = [ctypes.c_int() for _ in range(4)]
+    L.bg_ann_rom_limits(*[ctypes.byref(v) for v in lim])
+    max_n, max_nbar, max_w, max_l = (v.value for v in lim)
+    kinds = {type(None): _lib.BG_ACT_NONE, nn.ELU: _lib.BG_ACT_ELU, nn.ReLU: _lib.BG_ACT_RELU, nn.Tanh: _lib.BG_ACT_TANH}
+    widths = [ann.layers[0][0].in_features] + [lin.out_features for lin, _ in ann.layers]
+    if (n > max_n or nbar > max_nbar or len(ann.layers) > max_l or max(widths[1:]) > max_w or widths[0] != n
+            or widths[-1] != nbar or any(type(act) not in kinds for _, act in ann.layers)):
+        return None
+    f32 = dict(dtype=torch.float32, device=device)
+    # W^T zero-padded to [in rounded up to 4][out rounded up to 8]: a thread fetches the weights of 8 outputs of one input
+    # as two 16-byte loads, four inputs at a time, with no bounds checks in the kernel
+    wts = [torch.nn.functional.pad(lin.weight.detach().to(**f32).t(), (0, -lin.out_features % 8, 0, -lin.in_features % 4)).contiguous()
+           for lin, _ in ann.layers]
+    biases = [None if lin.bias is None else lin.bias.detach().to(**f32).contiguous() for lin, _ in ann.layers]
+    nl = len(wts)
+    return dict(
+        keep=(wts, biases), nl=nl,
+        widths=(ctypes.c_int * (nl + 1))(*widths),
+        wt=(ctypes.c_void_p * nl)(*[w.data_ptr() for w in wts]),
+        bias=(ctypes.c_void_p * nl)(*[None if b is None else b.data_ptr() for b in biases]),
+        acts=(ctypes.c_int * nl)(*[kinds[type(act)] for _, act in ann.layers]),
+        alphas=(ctypes.c_float * nl)(*[float(getattr(act, "alpha", 1.0)) for _, act in ann.layers]))
+
+
+def pod_ann_run_fused(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, proj, E=0.0, tol=1e-6, max_it=50, device=None,
+                      options=0, plan=None):
+    """``pod_ann_prom`` for a batch with the whole time loop on the device (bg_ann_rom_run): one workgroup per sample,
+    the closure MLP evaluated in-kernel in float32.  Returns None when the model is outside what that kernel covers."""
+    L = _lib.load()
+    device = _lib.require_device(device)
+    opts = _lib.mesh_options(check_mesh(X), supg=True) | options
+    Xd = _as_dev(X, device)
+    N = Xd.numel()
+    Up, Us = _as_dev(U_p, device), _as_dev(U_s, device)
+    if Up.dim() != 2 or Us.dim() != 2 or Up.shape[0] != N or Us.shape[0] != N:
+        raise ValueError("U_p and U_s must have one row per mesh node")
+    n, nbar = Up.shape[1], Us.shape[1]
+    if plan is None:
+        plan = _ann_fused_plan(model.to(device=device, dtype=torch.float32).eval(), n, nbar, N, torch.float32, device)
+    if plan is None:
+        return None
+    UpT, UsT = Up.t().contiguous(), Us.t().contiguous()
+    u0d, mu1d, mu2d = _batch_inputs(u0, mu1, mu2, N, device)
+    B = mu1d.numel()
+    hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
+    iters = torch.zeros((B, nsteps), dtype=torch.int32, device=device)
+    flags = torch.zeros((B,), dtype=torch.int32, device=device)
+    info = torch.zeros((B,), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        rc = L.bg_ann_rom_run(N, B, n, nbar, int(nsteps), proj, _lib.ptr(Xd), _lib.ptr(UpT), _lib.ptr(UsT), _lib.ptr(u0d),
+                              _lib.ptr(mu1d), _lib.ptr(mu2d), plan["nl"], plan["widths"], plan["wt"], plan["bias"],
+                              plan["acts"], plan["alphas"], float(dt), float(E), float(tol), int(max_it), int(opts),
+                              _lib.ptr(hist), _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(info), _lib.stream_ptr(device))
+    _lib.check(rc, "bg_ann_rom_run")
+    res = FomResult(hist, iters, flags)
+    res.info = info
+    res._keep = (plan, UpT, UsT, Xd, u0d, mu1d, mu2d)      # the launch is asynchronous: its operands live as long as the result
+    return res
+
+
 def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG", E=0.0, tol=1e-6, max_it=50,
-                device=None, ann_dtype=torch.float32):
+                device=None, ann_dtype=torch.float32, fused=True):
     """Batched ``pod_ann_prom``.  The MLP and its Jacobian are evaluated in ``ann_dtype`` (the
-    reference uses float32, :1219,:1241) through PyTorch-ROCm; everything else is fp64."""
+    reference uses float32, :1219,:1241); everything else is fp64.  ``fused`` (default): the device-side time loop
+    bg_ann_rom_run when the closure is a plain float32 MLP within bg_ann_rom_limits; otherwise, or with
+    ``fused=False``, the batched iteration driven from the host (MLP layers as GEMMs through PyTorch-ROCm)."""
     p = projection.lower()
     if p not in PROJ:
         raise ValueError("projection must be 'Galerkin' or 'LSPG'")
     proj = PROJ[p]
+    if fused and ann_dtype == torch.float32:
+        res = pod_ann_run_fused(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, proj, E, tol, max_it, device)
+        if res is not None:
+            return check_singular(res)
     c = _setup(X, u0, mu1, mu2, dt, E, device)
     Up, Us = _as_dev(U_p, c.device), _as_dev(U_s, c.device)
     n = Up.shape[1]

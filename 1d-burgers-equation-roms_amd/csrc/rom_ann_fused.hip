@@ -1,0 +1,550 @@
+// rom_ann_fused.hip -- the whole POD-ANN PROM time loop of one sample on one compute unit, and its C-ABI entry point.
+//
+// Replaces FEMBurgers.pod_ann_prom (reference FEM/fem_burgers.py:1177-1251, compute_ann_jacobian :1254-1275) for a batch of
+// samples when the closure is a plain MLP (Linear + ELU / ReLU / Tanh stacks, POD-ANN/pod_ann.py:38-56): one 256-thread
+// workgroup owns a sample for ALL time steps and Gauss-Newton iterations.  Per iteration, with no kernel boundary:
+//     assembly (2 rows per thread)
+//     -> projection of the tangent W = U_p + U_s dN on v_mfma_f64_4x4x4_4b (mfma_pass, as bg_rom_run; W lives in LDS)
+//     -> n x n solve (cooperative guarded Gauss-Jordan, n <= 8)            np.linalg.solve :1237
+//     -> q_p += dq, err = |dq| / (|q_p| + 1e-14), stopping test            :1238-1244
+//     -> closure at the new q_p: the MLP value N(q_p) AND its input-Jacobian in ONE forward-mode pass in float32 (the
+//        value and the n tangent directions are the 1 + n rows of a small matrix in LDS; a thread owns 4 outputs of a
+//        layer and a slice of its inputs, the weights stream from L2 as 16-byte loads of W^T) -- the reference evaluates both in float32 too
+//        (:1219, :1241) -- then ONE sweep over U_s^T that forms the decode u = U_p q_p + U_s N(q_p) (:1242) and the next
+//        iteration's tangent W = U_p + U_s dN (:1224) together, straight into LDS.
+// HBM sees u0 once and one N-row history write per time step; the MLP weights (0.5 MB) and U_s (0.4 MB) are re-read from
+// L2 every iteration.  Host-side the batched iteration of burgers_hip/rom.py needs ~40 dependent launches per iteration
+// for the same work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/burgers_hip.h"
+#include "abi_common.hpp"
+#include "rom_fused_device.hpp"
+
+namespace {
+
+using namespace bg;
+using namespace bg::fused;
+
+constexpr int ANN_MAX_LAYERS = 8;
+constexpr int ANN_MAX_WIDTH = 256;      // one thread per neuron
+constexpr int ANN_MAX_N = 8;            // reduced coordinates: two 4-column MFMA blocks
+constexpr int ANN_MAX_ROWS = 1 + ANN_MAX_N;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// a + (a of the neighbouring row) in the even rows of 16 lanes, b + (b of the neighbouring row) in the odd rows
+__device__ __forceinline__ float swap16_add(float a, float b)
+{
+    const auto t = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)t[0]) + __builtin_bit_cast(float, (unsigned)t[1]);
+}
+// a + (a of the other half) in lanes 0..31, b + (b of the other half) in lanes 32..63
+__device__ __forceinline__ float swap32_add(float a, float b)
+{
+    const auto t = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)t[0]) + __builtin_bit_cast(float, (unsigned)t[1]);
+}
+
+struct AnnRunArgs {
+    const double* x;        // [N]
+    const double* UpT;      // [n][N]      U_p^T
+    const double* UsT;      // [nbar][N]   U_s^T
+    const double* u0;       // [B][N]
+    const double* mu1;      // [B]
+    const double* mu2;      // [B]
+    double* hist;           // [B][nsteps+1][N]
+    int32_t* iters;         // [B][nsteps]
+    int32_t* flags;         // [B]
+    int32_t* info;          // [B]
+    const float* wt[ANN_MAX_LAYERS];     // layer l: W^T, [in4][ld] row-major: width[l] rounded up to 4 rows, width[l+1] to 8 columns, zero fill
+    const float* bias[ANN_MAX_LAYERS];   // [width[l+1]] or null
+    int width[ANN_MAX_LAYERS + 1];
+    int act[ANN_MAX_LAYERS];
+    float alpha[ANN_MAX_LAYERS];
+    int nl;
+    double dt, E, tol;
+    int N, B, n, nbar, nsteps, max_it, supg, nonuniform, force_pivoted;
+};
+
+template <int S, int PROJ, bool PIV>
+__global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
+{
+    constexpr int NB = 2;
+    constexpr int NPAD = 64 * S;
+    constexpr int RW = 4 * NB;
+    constexpr bool GAL = PROJ == BG_PROJ_GALERKIN;
+    __shared__ double s_u[NPAD + 4];             // u at offset 2, zero halo on each side
+    __shared__ double s_g[NPAD], s_h[NPAD];
+    __shared__ __attribute__((aligned(16))) double s_W[NPAD + 2][RW];      // tangent rows, row i at [i + 1]; zero rows around and beyond N
+    __shared__ double s_wtu[4][RW];
+    __shared__ double s_diag[RW], s_y[RW], s_q[RW], s_x[RW];
+    __shared__ double s_part[4][RW];             // per-wave partial sums of U_p^T u
+    __shared__ int s_bad[4];
+    __shared__ int s_info;
+    // The two halves of an iteration never overlap in time and share one block of LDS (two workgroups per CU need
+    // <= 80 KB each):  projection + solve: s_coef, s_halo, s_red, s_m   |   closure: s_act, s_dN, s_qs
+    constexpr int kCoefB = NPAD * 4 * 8, kHaloB = 2 * NB * 256 * 8, kRedB = 4 * RW * (RW + 4) * 8, kMB = 2 * 4 * 64 * 8;
+    constexpr int kActB = 2 * ANN_MAX_ROWS * ANN_MAX_WIDTH * 4, kDnB = 128 * RW * 8, kQsB = 128 * 8;
+    constexpr int kPhaseA = kCoefB + kHaloB + kRedB + kMB, kPhaseB = kActB + kDnB + kQsB;
+    __shared__ __attribute__((aligned(16))) unsigned char s_shared[kPhaseA > kPhaseB ? kPhaseA : kPhaseB];
+    auto& s_coef = *reinterpret_cast<double (*)[NPAD][4]>(s_shared);
+    auto& s_halo = *reinterpret_cast<double (*)[2][NB][256]>(s_shared + kCoefB);
+    auto& s_red = *reinterpret_cast<double (*)[4][RW][RW + 4]>(s_shared + kCoefB + kHaloB);
+    auto& s_m = *reinterpret_cast<double (*)[2][4][64]>(s_shared + kCoefB + kHaloB + kRedB);
+    auto& s_act = *reinterpret_cast<float (*)[2][ANN_MAX_ROWS][ANN_MAX_WIDTH]>(s_shared);   // MLP activations: value row + n tangent rows
+    auto& s_dN = *reinterpret_cast<double (*)[128][RW]>(s_shared + kActB);                  // dN/dq_p, zero beyond n
+    auto& s_qs = *reinterpret_cast<double (*)[128]>(s_shared + kActB + kDnB);               // N(q_p)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int t = lane & 3, owner = 16 * w + (lane >> 2);
+    const int N = a.N, n = a.n, nbar = a.nbar, nr = 1 + a.n;
+    const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
+    const int rowbase = owner * S;
+    const int i0 = tid, i1 = tid + 256;          // the two mesh rows of this thread in the row-wise passes
+
+    if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;
+    for (int e = tid; e < (NPAD + 2) * RW; e += 256) (&s_W[0][0])[e] = 0.0;
+    if (tid < RW) s_q[tid] = 0.0;
+
+    // ---- N(q_p) and dN/dq_p at q_p = s_q, float32 forward mode: rows 0 = value, 1 .. n = tangent directions --------
+    // ---- N(q_p) and dN/dq_p at q_p = s_q, float32 forward mode: rows 0 = value, 1 .. n = tangent directions --------
+    // Layer l on all 256 threads.  A thread owns 8 outputs (two 16-byte weight loads per input k, no guards: the host
+    // pads W^T to [in4][ld]) and every KPw-th group of 4 inputs; lane = (input slice) * P + (output group), so that
+    // neighbouring lanes read neighbouring 16-byte chunks of a weight row.  NRT = rows compiled in.
+    auto mlp_impl = [&](auto nrt_c) __attribute__((always_inline)) {
+        constexpr int NRT = decltype(nrt_c)::value;
+        int cur = 0;
+        if (tid < RW) {                                              // inputs padded with zeros to a multiple of 4
+            s_act[0][0][tid] = tid < n ? (float)s_q[tid] : 0.0f;
+#pragma unroll
+            for (int r = 1; r < ANN_MAX_ROWS; ++r) s_act[0][r][tid] = (r - 1 == tid && tid < n) ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        for (int l = 0; l < (skip(128) ? 0 : a.nl); ++l) {          // (128: timing builds only)
+            const int in4 = (a.width[l] + 3) & ~3, out = a.width[l + 1], ldw = (out + 7) & ~7, ogn = ldw >> 3;
+            int P = 1, pshift = 0;
+            while (4 * P < ogn) { P <<= 1; ++pshift; }                // output groups per wave (a power of two, <= 8)
+            int KPw = 64 >> pshift;                                   // input slices per wave ...
+            while (4 * KPw > in4 && KPw > 1) KPw >>= 1;               // ... at most one per group of 4 inputs (small layers)
+            const int span = P * KPw;                                 // lanes of a wave that carry partial sums
+            const int kp = lane >> pshift, ogr = w * P + (lane & (P - 1));    // neighbouring lanes: neighbouring 16-byte chunks
+            const int og = ogr < ogn ? ogr : ogn - 1;                 // spare lanes redo the last group (no guarded loads)
+            // the 8 outputs of a thread are two chunks of 4: [4 og, 4 og + 4) and the same in the second half of the row
+            const float* __restrict__ wp = a.wt[l] + 4 * og;
+            const int half = 4 * ogn;
+            float acc[NRT][8];
+#pragma unroll
+            for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[r][c] = 0.0f;
+            auto kload = [&](int kb, float4 (&wv)[4][2]) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float4* src = reinterpret_cast<const float4*>(wp + (size_t)(kb + kk) * ldw);
+                    if constexpr (skip(1024)) {                          // timing only: no weight traffic
+                        wv[kk][0] = make_float4(1.0f * kb, 2.0f, 3.0f, 4.0f); wv[kk][1] = wv[kk][0];
+                    } else {
+                        wv[kk][0] = src[0];
+                        wv[kk][1] = src[ogn];
+                    }
+                }
+            };
+            auto kfma = [&](int kb, const float4 (&wv)[4][2]) {
+#pragma unroll
+                for (int r = 0; r < (skip(512) ? 1 : NRT); ++r) {      // (512: timing only: weight traffic, one row of arithmetic)
+                    const float4 xv = *reinterpret_cast<const float4*>(&s_act[cur][r][kb]);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        acc[r][0] = __builtin_fmaf(xs[kk], wv[kk][0].x, acc[r][0]); acc[r][1] = __builtin_fmaf(xs[kk], wv[kk][0].y, acc[r][1]);
+                        acc[r][2] = __builtin_fmaf(xs[kk], wv[kk][0].z, acc[r][2]); acc[r][3] = __builtin_fmaf(xs[kk], wv[kk][0].w, acc[r][3]);
+                        acc[r][4] = __builtin_fmaf(xs[kk], wv[kk][1].x, acc[r][4]); acc[r][5] = __builtin_fmaf(xs[kk], wv[kk][1].y, acc[r][5]);
+                        acc[r][6] = __builtin_fmaf(xs[kk], wv[kk][1].z, acc[r][6]); acc[r][7] = __builtin_fmaf(xs[kk], wv[kk][1].w, acc[r][7]);
+                    }
+                }
+            };
+            const int kstride = 4 * KPw;
+            int kb = kp < KPw ? 4 * kp : in4;                         // lanes beyond the span hold zeros and stay out of the fold
+            if constexpr (NRT <= 6) {                                 // two slices per trip: 16 weight loads in flight
+                for (; kb + kstride < in4; kb += 2 * kstride) {
+                    float4 wa[4][2], wb[4][2];
+                    kload(kb, wa);
+                    kload(kb + kstride, wb);
+                    kfma(kb, wa);
+                    kfma(kb + kstride, wb);
+                }
+            }
+            for (; kb < in4; kb += kstride) {
+                float4 wa[4][2];
+                kload(kb, wa);
+                kfma(kb, wa);
+            }
+            // fold the KPw input slices (lanes P apart): inside a row of 16 lanes with shifts towards the higher lanes, so
+            // the row total lands in its last P lanes; across the four rows with ds_bpermute
+            auto fold = [&](auto get) {
+                if constexpr (skip(2048)) return;                     // timing only
+#pragma unroll
+                for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[r][c] += get(acc[r][c]);
+            };
+            if (P <= 1 && span > 1) fold([](float v) { return dpp_f32<0x111>(v); });      // row_shr:1
+            if (P <= 2 && span > 2) fold([](float v) { return dpp_f32<0x112>(v); });      // row_shr:2
+            if (P <= 4 && span > 4) fold([](float v) { return dpp_f32<0x114>(v); });      // row_shr:4
+            if (span > 8) fold([](float v) { return dpp_f32<0x118>(v); });                // row_shr:8
+            const int half_og = half + 4 * og;
+            if (NRT == 6 && span == 64 && !skip(2048)) {
+                // Across the four rows of 16 lanes with v_permlane16_swap / v_permlane32_swap (VALU; ds_bpermute would make
+                // the LDS pipe the bottleneck): the 12 chunks of 4 outputs (6 rows x 2) are folded four at a time, and
+                // row rho of the wave ends up with the totals of chunk 4 g + rho -- all four rows store.
+                const int rho = lane >> 4;
+                float res[3][4];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // chunk u = 2 r + (first | second half of the row) -> acc[u >> 1][4 (u & 1) + e]
+                        const float s01 = swap16_add(acc[(4 * g) >> 1][e], acc[(4 * g + 1) >> 1][4 + e]);
+                        const float s23 = swap16_add(acc[(4 * g + 2) >> 1][e], acc[(4 * g + 3) >> 1][4 + e]);
+                        res[g][e] = swap32_add(s01, s23);
+                    }
+                }
+                if ((lane & 15) >= 16 - P && ogr < ogn) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        const int u = 4 * g + rho;
+                        *reinterpret_cast<float4*>(&s_act[cur ^ 1][u >> 1][(u & 1) ? half_og : 4 * og]) =
+                            make_float4(res[g][0], res[g][1], res[g][2], res[g][3]);
+                    }
+                }
+            } else {
+                if (span > 16) fold([](float v) { return __shfl_xor(v, 16); });
+                if (span > 32) fold([](float v) { return __shfl_xor(v, 32); });
+                const int top = span < 16 ? span : 16;                // the totals sit in the last P lanes below `top`
+                if (lane >= top - P && lane < top && ogr < ogn) {     // pre-activations of 8 outputs, all rows
+#pragma unroll
+                    for (int r = 0; r < NRT; ++r) {
+                        *reinterpret_cast<float4*>(&s_act[cur ^ 1][r][4 * og]) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+                        *reinterpret_cast<float4*>(&s_act[cur ^ 1][r][half_og]) = make_float4(acc[r][4], acc[r][5], acc[r][6], acc[r][7]);
+                    }
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+            if (tid < ldw && !skip(4096)) {
+                // bias, activation, derivative scaling, one output per thread: the arithmetic of bg_mlp_act_jvp (csrc/mlp.hip)
+                const int kind = a.act[l];
+                const float alpha = a.alpha[l];
+                const bool real = tid < out;
+                const float v = s_act[cur][0][tid] + ((real && a.bias[l]) ? a.bias[l][tid] : 0.0f);
+                float av = v, d = 1.0f;
+                if (kind == BG_ACT_ELU) {
+                    const float e = alpha * expf(v);
+                    av = v > 0.0f ? v : e - alpha;
+                    d = v > 0.0f ? 1.0f : e;
+                } else if (kind == BG_ACT_RELU) {
+                    av = v > 0.0f ? v : 0.0f;
+                    d = v > 0.0f ? 1.0f : 0.0f;
+                } else if (kind == BG_ACT_TANH) {
+                    av = tanhf(v);
+                    d = 1.0f - av * av;
+                }
+                if (!real) { av = 0.0f; d = 0.0f; }                   // the padding outputs feed the next layer's padded inputs
+                s_act[cur][0][tid] = av;
+                if (kind != BG_ACT_NONE || !real) {
+#pragma unroll
+                    for (int r = 1; r < NRT; ++r) s_act[cur][r][tid] *= d;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid < nbar) {
+            s_qs[tid] = (double)s_act[cur][0][tid];
+#pragma unroll
+            for (int c = 0; c < ANN_MAX_N; ++c) s_dN[tid][c] = (c < n && 1 + c < NRT) ? (double)s_act[cur][1 + c][tid] : 0.0;
+            if (n <= 5) s_dN[tid][5] = s_qs[tid];                       // [dN_0..4 | N]: three 16-byte reads per mode in the sweep
+        }
+        __syncthreads();
+    };
+    auto mlp = [&]() __attribute__((always_inline)) {
+        if (nr <= 6) mlp_impl(std::integral_constant<int, 6>{});
+        else mlp_impl(std::integral_constant<int, ANN_MAX_ROWS>{});
+    };
+
+    // ---- one sweep over U_s^T (and U_p^T): tangent W = U_p + U_s dN into s_W, and (decode) u = U_p q_p + U_s N(q_p) ----
+    // Straight-line: NC columns compiled in (dN and q_p are zero beyond n), rows beyond N read row N - 1 and are dropped.
+    auto closure_impl = [&](auto nc_c, bool decode) __attribute__((always_inline)) {
+        constexpr int NC = decltype(nc_c)::value;
+        const bool in0 = i0 < N, in1 = i1 < N;
+        const int r0 = in0 ? i0 : N - 1, r1 = in1 ? i1 : N - 1;
+        double u0v = 0.0, u1v = 0.0, w0[NC], w1[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int cc = c < n ? c : n - 1;
+            const double p0 = a.UpT[(size_t)cc * N + r0], p1 = a.UpT[(size_t)cc * N + r1];
+            const double qc = s_q[c];                                   // zero beyond n
+            w0[c] = c < n ? p0 : 0.0; w1[c] = c < n ? p1 : 0.0;
+            u0v = __builtin_fma(p0, qc, u0v); u1v = __builtin_fma(p1, qc, u1v);
+        }
+        auto mode = [&](int j, double s0, double s1) {
+            const double qs = NC <= 5 ? s_dN[j][5] : s_qs[j];
+            u0v = __builtin_fma(s0, qs, u0v); u1v = __builtin_fma(s1, qs, u1v);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double dn = s_dN[j][c];
+                w0[c] = __builtin_fma(s0, dn, w0[c]);
+                w1[c] = __builtin_fma(s1, dn, w1[c]);
+            }
+        };
+        const int nb8 = skip(256) ? 0 : (nbar & ~7);                  // (256: timing builds only)
+        for (int jb = 0; jb < nb8; jb += 8) {
+            double s0[8], s1[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {                           // 16 loads in flight
+                s0[jj] = a.UsT[(size_t)(jb + jj) * N + r0];
+                s1[jj] = a.UsT[(size_t)(jb + jj) * N + r1];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) mode(jb + jj, s0[jj], s1[jj]);
+        }
+        for (int j = nb8; j < (skip(256) ? 0 : nbar); ++j) mode(j, a.UsT[(size_t)j * N + r0], a.UsT[(size_t)j * N + r1]);
+#pragma unroll
+        for (int c = 0; c < RW; ++c) {
+            double v0 = 0.0, v1 = 0.0;
+            if (c < NC) { v0 = w0[c < NC ? c : 0]; v1 = w1[c < NC ? c : 0]; }
+            if (i0 < NPAD) s_W[i0 + 1][c] = in0 ? v0 : 0.0;
+            if (i1 < NPAD) s_W[i1 + 1][c] = in1 ? v1 : 0.0;
+        }
+        if (decode) {
+            if (i0 < NPAD) s_u[i0 + 2] = in0 ? u0v : 0.0;
+            if (i1 < NPAD) s_u[i1 + 2] = in1 ? u1v : 0.0;
+        }
+        __syncthreads();
+    };
+    auto closure = [&](bool decode) __attribute__((always_inline)) {
+        if (n <= 5) closure_impl(std::integral_constant<int, 5>{}, decode);
+        else closure_impl(std::integral_constant<int, ANN_MAX_N>{}, decode);
+    };
+
+    for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
+        if (PIV && !a.force_pivoted && a.info[smp] != BG_INFO_NEEDS_PIVOTING) continue;      // workgroup-uniform
+        const double mu1 = a.mu1[smp], mu2 = a.mu2[smp];
+        double* hist = a.hist + (size_t)smp * (size_t)(a.nsteps + 1) * (size_t)N;
+        __syncthreads();
+        // ---- per-sample constants (compute_forcing_vector :427-461, f_gp of :556-558) and the initial state ----------
+        double fdt[S / 4];                          // dt F of this thread's rows i = tid (+ 256)
+#pragma unroll
+        for (int ii = 0; ii < S / 4; ++ii) {
+            const int i = tid + 256 * ii;
+            double frPrev = 0.0, fl = 0.0, hf = 0.0, u = 0.0;
+            if (i < N) {
+                if (i > 0) {
+                    const double xl = a.x[i - 1], xr = a.x[i];
+                    const double he = a.nonuniform ? xr - xl : h;
+                    const double f1 = 0.02 * exp(mu2 * (GP_A * xl + GP_B * xr));
+                    const double f2 = 0.02 * exp(mu2 * (GP_B * xl + GP_A * xr));
+                    frPrev = (f1 * GP_B + f2 * GP_A) * (0.5 * he);
+                }
+                if (i < N - 1) {
+                    const double xl = a.x[i], xr = a.x[i + 1];
+                    const double he = a.nonuniform ? xr - xl : h;
+                    const double f1 = 0.02 * exp(mu2 * (GP_A * xl + GP_B * xr));
+                    const double f2 = 0.02 * exp(mu2 * (GP_B * xl + GP_A * xr));
+                    fl = (f1 * GP_A + f2 * GP_B) * (0.5 * he);
+                    hf = he * (f1 + f2);
+                }
+                u = a.u0[(size_t)smp * N + i];
+                hist[i] = u;
+            }
+            fdt[ii] = a.dt * (frPrev + fl);
+            s_h[i] = hf;
+            s_u[i + 2] = u;
+        }
+        __syncthreads();
+
+        int flags = 0, info_out = 0;
+        bool aborted = false;
+        for (int step = 0; step < a.nsteps && info_out == 0 && !aborted; ++step) {
+            // ---- g = M u^n + dt F (:1214) and q_p = U_p^T u^n (:1197) --------------------------------------------------
+            {
+                double part[ANN_MAX_N];
+#pragma unroll
+                for (int c = 0; c < ANN_MAX_N; ++c) part[c] = 0.0;
+#pragma unroll
+                for (int ii = 0; ii < S / 4; ++ii) {
+                    const int i = tid + 256 * ii;
+                    double g = 0.0;
+                    if (i < N) {
+                        const double um = s_u[i + 1], uc = s_u[i + 2], ur = s_u[i + 3];
+                        if (a.nonuniform) {
+                            double v = 0.0;
+                            if (i > 0) v = (a.x[i] - a.x[i - 1]) / 6.0 * __builtin_fma(2.0, uc, um);
+                            if (i < N - 1) v = __builtin_fma((a.x[i + 1] - a.x[i]) / 6.0, __builtin_fma(2.0, uc, ur), v);
+                            g = v + fdt[ii];
+                        } else {
+                            double acc;
+                            if (i == 0) acc = __builtin_fma(2.0, uc, ur);
+                            else if (i == N - 1) acc = __builtin_fma(2.0, uc, um);
+                            else acc = __builtin_fma(4.0, uc, um) + ur;
+                            g = __builtin_fma(h / 6.0, acc, fdt[ii]);
+                        }
+#pragma unroll
+                        for (int c = 0; c < ANN_MAX_N; ++c)
+                            if (c < n) part[c] = __builtin_fma(a.UpT[(size_t)c * N + i], uc, part[c]);
+                    }
+                    s_g[i] = g;
+                }
+#pragma unroll
+                for (int c = 0; c < ANN_MAX_N; ++c) {
+                    if (c < n) {
+                        const double sm = wave_sum(part[c]);
+                        if (lane == 0) s_part[w][c] = sm;
+                    }
+                }
+                __syncthreads();
+                if (tid < RW) s_q[tid] = (tid < n) ? (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]) : 0.0;
+                __syncthreads();
+            }
+            int k = 0;
+            bool more = true, decode = false;
+            while (true) {
+                // ---- closure at the current q_p (one call site: the code is inlined once).  First pass of a time step:
+                // dN at the first guess (:1219), tangent only, U0 stays u^n.  Later passes: q_s = N(q_p) for the decode
+                // (:1241-1242) and dN for the next projection (:1219-1224).
+                mlp();
+                closure(decode);
+                if (!more) break;
+                decode = true;
+                // ---- assembly: A(u_k), R(u_k) per row into LDS ----------------------------------------------------
+                for (int i = tid; i < (skip(16) ? 0 : NPAD); i += 256) {
+                    double lo, di, up, R;
+                    const bool in = i < N;
+                    const MeshConst mc = make_mesh_const(h, a.dt, a.E, a.supg);
+                    rom_assemble_row(i, N, s_u[i + 1], s_u[i + 2], (i + 1 < N) ? s_u[i + 3] : 0.0, in ? s_g[i] : 0.0,
+                                     (in && i > 0) ? s_h[i - 1] : 0.0, (in && i < N - 1) ? s_h[i] : 0.0, mu1, mc,
+                                     a.nonuniform, a.x, a.dt, a.E, lo, di, up, R);
+                    s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = R;
+                }
+                // ---- tangent fragments of this lane from LDS (the tangent changes every iteration) ----------------
+                double frag[NB][S];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) frag[c][s] = s_W[rowbase + s + 1][4 * c + t];
+                    s_halo[0][c][tid] = s_W[rowbase][4 * c + t];
+                    s_halo[1][c][tid] = s_W[rowbase + S + 1][4 * c + t];
+                }
+                __syncthreads();
+                if constexpr (!skip(1))
+                    mfma_pass<S, NB, GAL, 0, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
+                __syncthreads();
+                // ---- reduced solve -------------------------------------------------------------------------------
+                double xout = 0.0;
+                if constexpr (PIV) {
+                    if (tid == 0) s_info = 0;
+                    __syncthreads();
+                    if (w == 0) pivoted_solve<NB, GAL>(s_red, s_x, &s_info, lane, n);
+                    __syncthreads();
+                    xout = (lane < RW) ? s_x[lane] : 0.0;
+                    if (s_info != 0 && info_out == 0) info_out = s_info;
+                } else {
+                    bool tripped;
+                    xout = coop_gj_solve<NB, GAL, !skip(2)>(s_red, s_m, s_diag, s_y, s_bad, w, lane, n, tripped);
+                    if (!kTiming && tripped) aborted = true;
+                }
+                // ---- q_p += dq, err = |dq| / (|q_p| + 1e-14)  (:1238-1244) -----------------------------------------
+                const double dq = (lane < n) ? xout : 0.0;
+                const double qn = (lane < n) ? s_q[lane] + dq : 0.0;
+                double nd, nq;
+                wave_sum2(dq * dq, qn * qn, nd, nq);
+                nd = sqrt(nd); nq = sqrt(nq);
+                const double err = nd / (nq + 1e-14);
+                ++k;
+                more = (err > a.tol) && (k < a.max_it) && info_out == 0 && !aborted;
+                if (kTiming) more = k < 5;
+                if (!(err - err == 0.0)) flags |= BG_FLAG_NONFINITE;
+                if (k >= a.max_it) flags |= BG_FLAG_HIT_CAP;
+                __syncthreads();                                   // every wave has read s_q
+                if (w == 0 && lane < RW) s_q[lane] = qn;
+                __syncthreads();
+            }
+            double* hrow = hist + (size_t)(step + 1) * N;
+            for (int i = tid; i < N; i += 256) hrow[i] = s_u[i + 2];
+            if (tid == 0) a.iters[(size_t)smp * a.nsteps + step] = k;
+        }
+        if (tid == 0) {
+            a.flags[smp] = flags;
+            a.info[smp] = aborted ? BG_INFO_NEEDS_PIVOTING : info_out;
+        }
+    }
+}
+
+template <int S, bool PIV>
+void launch_ann(int projection, int grid, hipStream_t st, const AnnRunArgs& a)
+{
+    if (projection == BG_PROJ_GALERKIN)
+        hipLaunchKernelGGL((rom_ann_fused_kernel<S, BG_PROJ_GALERKIN, PIV>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((rom_ann_fused_kernel<S, BG_PROJ_LSPG, PIV>), dim3(grid), dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bg_ann_rom_limits(int* max_n, int* max_nbar, int* max_width, int* max_layers)
+{
+    if (max_n) *max_n = ANN_MAX_N;
+    if (max_nbar) *max_nbar = 128;
+    if (max_width) *max_width = ANN_MAX_WIDTH;
+    if (max_layers) *max_layers = ANN_MAX_LAYERS;
+    return BG_OK;
+}
+
+int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, const double* x, const double* UpT,
+                   const double* UsT, const double* u0, const double* mu1, const double* mu2, int n_layers,
+                   const int* widths, const float* const* wt, const float* const* bias, const int* acts,
+                   const float* alphas, double dt, double E, double tol, int max_it, int options, double* hist,
+                   int32_t* iters, int32_t* flags, int32_t* info, void* stream)
+{
+    if (N < 2 || B < 0 || n < 1 || nbar < 1 || nsteps < 0 || max_it < 1 || !(dt > 0.0) || n_layers < 1) return BG_ERR_BAD_ARG;
+    if (projection != BG_PROJ_GALERKIN && projection != BG_PROJ_LSPG) return BG_ERR_PROJECTION;
+    if (N > 512) return BG_ERR_UNSUPPORTED_N;
+    if (n > ANN_MAX_N || nbar > 128 || n_layers > ANN_MAX_LAYERS) return BG_ERR_UNSUPPORTED_R;
+    if (!widths || !wt || !bias || !acts || !alphas) return BG_ERR_BAD_ARG;
+    if (widths[0] != n || widths[n_layers] != nbar) return BG_ERR_BAD_ARG;
+    AnnRunArgs a;
+    for (int l = 0; l < n_layers; ++l) {
+        if (widths[l + 1] < 1 || widths[l + 1] > ANN_MAX_WIDTH) return BG_ERR_UNSUPPORTED_R;
+        if (!wt[l] || ((uintptr_t)wt[l] & 15)) return BG_ERR_BAD_ARG;
+        if (acts[l] != BG_ACT_NONE && acts[l] != BG_ACT_ELU && acts[l] != BG_ACT_RELU && acts[l] != BG_ACT_TANH) return BG_ERR_BAD_ARG;
+        a.wt[l] = wt[l]; a.bias[l] = bias[l]; a.act[l] = acts[l]; a.alpha[l] = alphas[l];
+    }
+    for (int l = 0; l <= n_layers; ++l) a.width[l] = widths[l];
+    if (B == 0) return BG_OK;
+    if (!x || !UpT || !UsT || !u0 || !mu1 || !mu2 || !hist || !flags || !info || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
+    a.x = x; a.UpT = UpT; a.UsT = UsT; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
+    a.info = info; a.nl = n_layers; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.B = B; a.n = n; a.nbar = nbar;
+    a.nsteps = nsteps; a.max_it = max_it; a.supg = options & BG_OPT_SUPG; a.nonuniform = (options & BG_OPT_NONUNIFORM) ? 1 : 0;
+    a.force_pivoted = (options & BG_OPT_FORCE_PIVOTED) ? 1 : 0;
+    const int slots = 2 * device_cu_count();         // two workgroups per CU: one's memory latency hides behind the other
+    const int grid = B < slots ? B : slots;
+    hipStream_t st = (hipStream_t)stream;
+    const bool small = N <= 256;
+    if (!a.force_pivoted) {
+        if (small) launch_ann<4, false>(projection, grid, st, a); else launch_ann<8, false>(projection, grid, st, a);
+        const int rc = check_launch();
+        if (rc != BG_OK) return rc;
+    }
+    launch_ann<8, true>(projection, grid, st, a);       // repair kernel: returns at once unless a sample is marked
+    return check_launch();
+}
+
+}  // extern "C"

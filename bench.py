@@ -286,7 +286,7 @@ class RomWorkload(Workload):
 
 
 class PodWorkload(RomWorkload):
-    kernel_name = "rom_reduce4_kernel + lu_solve_kernel (per batched iteration)"
+    kernel_name = "rom_fused_kernel (bg_rom_run: one launch per pass, the whole time loop of a sample per workgroup)"
 
     def __init__(self, *a):
         super().__init__(*a)
@@ -344,7 +344,7 @@ class QuadWorkload(RomWorkload):
 
 class AnnWorkload(RomWorkload):
     kind = "ann"
-    kernel_name = "MLP fwd+JVP graph + tangent GEMM + rom_reduce4_kernel + lu_solve_kernel (per batched iteration)"
+    kernel_name = "rom_ann_fused_kernel (bg_ann_rom_run: one launch per pass, the whole time loop of a sample per workgroup)"
     dtype = "f64 (MLP closure f32, as the reference)"
 
     def __init__(self, *a):

@@ -278,6 +278,33 @@ int bg_rom_reduce_frag(int N, int B, int r, int projection, const double *x, con
  *   act    BG_ACT_NONE | BG_ACT_ELU (alpha) | BG_ACT_RELU | BG_ACT_TANH */
 int bg_mlp_act_jvp(int B, int n1, int h, float *z, const float *bias, int act, float alpha, void *stream);
 
+/* ---------------------------------------------------------------------------------
+ * bg_ann_rom_run -- batched replacement of FEMBurgers.pod_ann_prom, the WHOLE time loop on the device
+ *   reference: FEM/fem_burgers.py:1177-1251 (loop), compute_ann_jacobian :1254-1275, model POD-ANN/pod_ann.py:38-56.
+ *   One workgroup owns one sample for all time steps and Gauss-Newton iterations: assembly, fp64-MFMA projection of the
+ *   tangent W = U_p + U_s dN (:1224), the n x n solve (:1237), q_p += dq with err = |dq| / (|q_p| + 1e-14) (:1238-1244),
+ *   the closure N(q_p) with its input-Jacobian in one float32 forward-mode pass (the reference evaluates the model in
+ *   float32 too), and the decode u = U_p q_p + U_s N(q_p) (:1242).  At the start of a time step q_p = U_p^T u (:1197).
+ *   UpT    [n][N]    U_p^T, row-major (columns of U_p contiguous);  n <= 8
+ *   UsT    [nbar][N] U_s^T;                                         nbar <= 128, N <= 512
+ *   the closure, layer l = 0 .. n_layers-1 (n_layers <= 8), all four arrays HOST arrays of length n_layers (widths:
+ *   n_layers + 1, widths[0] = n, widths[n_layers] = nbar, every width <= 256):
+ *     wt[l]    DEVICE pointer, 16-byte aligned, float32 [in4][ld] row-major = the TRANSPOSE of torch's Linear.weight
+ *              zero-padded to in4 = widths[l] rounded up to 4 rows and ld = widths[l+1] rounded up to 8 columns (a thread
+ *              fetches the weights of 8 outputs of one input as two 16-byte loads, unguarded)
+ *     bias[l]  DEVICE pointer, float32 [widths[l+1]], or NULL
+ *     acts[l]  BG_ACT_* applied after layer l, alphas[l] its ELU alpha
+ *   limits are reported by bg_ann_rom_limits; a model outside them returns BG_ERR_UNSUPPORTED_R (use the per-iteration
+ *   entry points bg_mlp_act_jvp + bg_rom_reduce + bg_lu_solve_update instead).
+ *   u0, mu1, mu2, hist, iters, flags, info, options and the pivoting rule: as bg_rom_run.
+ * --------------------------------------------------------------------------------- */
+int bg_ann_rom_limits(int *max_n, int *max_nbar, int *max_width, int *max_layers);
+int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, const double *x, const double *UpT,
+                   const double *UsT, const double *u0, const double *mu1, const double *mu2, int n_layers,
+                   const int *widths, const float *const *wt, const float *const *bias, const int *acts,
+                   const float *alphas, double dt, double E, double tol, int max_it, int options, double *hist,
+                   int32_t *iters, int32_t *flags, int32_t *info, void *stream);
+
 /* bg_jacobi_sweep -- n_steps steps of a one-sided (Hestenes) Jacobi SVD sweep, the accurate small core of
  * the snapshot SVD (reference: np.linalg.svd at POD/pod.py:84, build_quadratic_manifold.py:29).
  *   G      [m][ld] row-major: the m rows are orthogonalised in place by plane rotations
