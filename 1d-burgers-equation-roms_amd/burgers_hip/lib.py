@@ -104,7 +104,7 @@ _SIGNATURES = {
     "bg_ann_rom_limits": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)] * 4),
     # widths / acts (int[]), wt / bias (void*[]) and alphas (float[]) are HOST arrays built by the caller
     "bg_ann_rom_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                      c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_int,
+                                      c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_int,
                                       ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
                                       ctypes.POINTER(ctypes.c_float), ctypes.c_double, ctypes.c_double, ctypes.c_double,

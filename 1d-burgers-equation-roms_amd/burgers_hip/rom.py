@@ -714,7 +714,9 @@ def pod_ann_run_fused(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, proj, E=0.0,
         plan = _ann_fused_plan(model.to(device=device, dtype=torch.float32).eval(), n, nbar, N, torch.float32, device)
     if plan is None:
         return None
-    UpT, UsT = Up.t().contiguous(), Us.t().contiguous()
+    UT = torch.zeros((-(-(n + nbar) // 8) * 8, N), dtype=torch.float64, device=device)     # [U_p^T; U_s^T; zero rows]
+    UT[:n] = Up.t()
+    UT[n:n + nbar] = Us.t()
     u0d, mu1d, mu2d = _batch_inputs(u0, mu1, mu2, N, device)
     B = mu1d.numel()
     hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
@@ -722,14 +724,14 @@ def pod_ann_run_fused(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, proj, E=0.0,
     flags = torch.zeros((B,), dtype=torch.int32, device=device)
     info = torch.zeros((B,), dtype=torch.int32, device=device)
     with torch.cuda.device(device):
-        rc = L.bg_ann_rom_run(N, B, n, nbar, int(nsteps), proj, _lib.ptr(Xd), _lib.ptr(UpT), _lib.ptr(UsT), _lib.ptr(u0d),
+        rc = L.bg_ann_rom_run(N, B, n, nbar, int(nsteps), proj, _lib.ptr(Xd), _lib.ptr(UT), _lib.ptr(u0d),
                               _lib.ptr(mu1d), _lib.ptr(mu2d), plan["nl"], plan["widths"], plan["wt"], plan["bias"],
                               plan["acts"], plan["alphas"], float(dt), float(E), float(tol), int(max_it), int(opts),
                               _lib.ptr(hist), _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(info), _lib.stream_ptr(device))
     _lib.check(rc, "bg_ann_rom_run")
     res = FomResult(hist, iters, flags)
     res.info = info
-    res._keep = (plan, UpT, UsT, Xd, u0d, mu1d, mu2d)      # the launch is asynchronous: its operands live as long as the result
+    res._keep = (plan, UT, Xd, u0d, mu1d, mu2d)      # the launch is asynchronous: its operands live as long as the result
     return res
 
 

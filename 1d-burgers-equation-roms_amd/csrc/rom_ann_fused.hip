@@ -54,8 +54,7 @@ __device__ __forceinline__ float swap32_add(float a, float b)
 
 struct AnnRunArgs {
     const double* x;        // [N]
-    const double* UpT;      // [n][N]      U_p^T
-    const double* UsT;      // [nbar][N]   U_s^T
+    const double* UT;       // [m8][N]: rows 0 .. n-1 = U_p^T, rows n .. n+nbar-1 = U_s^T, zero rows up to m8 = (n + nbar) rounded up to 8
     const double* u0;       // [B][N]
     const double* mu1;      // [B]
     const double* mu2;      // [B]
@@ -91,7 +90,8 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
     // The two halves of an iteration never overlap in time and share one block of LDS (two workgroups per CU need
     // <= 80 KB each):  projection + solve: s_coef, s_halo, s_red, s_m   |   closure: s_act, s_dN, s_qs
     constexpr int kCoefB = NPAD * 4 * 8, kHaloB = 2 * NB * 256 * 8, kRedB = 4 * RW * (RW + 4) * 8, kMB = 2 * 4 * 64 * 8;
-    constexpr int kActB = 2 * ANN_MAX_ROWS * ANN_MAX_WIDTH * 4, kDnB = 128 * RW * 8, kQsB = 128 * 8;
+    constexpr int kModes = 128 + ANN_MAX_N;       // secondary + primary modes of the sweep
+    constexpr int kActB = 2 * ANN_MAX_ROWS * ANN_MAX_WIDTH * 4, kDnB = kModes * RW * 8, kQsB = kModes * 8;
     constexpr int kPhaseA = kCoefB + kHaloB + kRedB + kMB, kPhaseB = kActB + kDnB + kQsB;
     __shared__ __attribute__((aligned(16))) unsigned char s_shared[kPhaseA > kPhaseB ? kPhaseA : kPhaseB];
     auto& s_coef = *reinterpret_cast<double (*)[NPAD][4]>(s_shared);
@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
     auto& s_red = *reinterpret_cast<double (*)[4][RW][RW + 4]>(s_shared + kCoefB + kHaloB);
     auto& s_m = *reinterpret_cast<double (*)[2][4][64]>(s_shared + kCoefB + kHaloB + kRedB);
     auto& s_act = *reinterpret_cast<float (*)[2][ANN_MAX_ROWS][ANN_MAX_WIDTH]>(s_shared);   // MLP activations: value row + n tangent rows
-    auto& s_dN = *reinterpret_cast<double (*)[128][RW]>(s_shared + kActB);                  // dN/dq_p, zero beyond n
-    auto& s_qs = *reinterpret_cast<double (*)[128]>(s_shared + kActB + kDnB);               // N(q_p)
+    auto& s_dN = *reinterpret_cast<double (*)[kModes][RW]>(s_shared + kActB);               // mode j of the sweep: d(coefficient j)/dq_p, zero beyond n
+    auto& s_qs = *reinterpret_cast<double (*)[kModes]>(s_shared + kActB + kDnB);            // coefficient j: q_p, then N(q_p), then zeros
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int t = lane & 3, owner = 16 * w + (lane >> 2);
-    const int N = a.N, n = a.n, nbar = a.nbar, nr = 1 + a.n;
+    const int N = a.N, n = a.n, nbar = a.nbar, nr = 1 + a.n, m8 = (a.n + a.nbar + 7) & ~7;
     const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
     const int rowbase = owner * S;
     const int i0 = tid, i1 = tid + 256;          // the two mesh rows of this thread in the row-wise passes
@@ -139,6 +139,8 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
             // the 8 outputs of a thread are two chunks of 4: [4 og, 4 og + 4) and the same in the second half of the row
             const float* __restrict__ wp = a.wt[l] + 4 * og;
             const int half = 4 * ogn;
+            // this thread's bias for the activation stage, fetched now so that its latency hides behind the layer
+            const float bias_v = a.bias[l] ? a.bias[l][tid < out ? tid : out - 1] : 0.0f;
             float acc[NRT][8];
 #pragma unroll
             for (int r = 0; r < NRT; ++r)
@@ -170,9 +172,11 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                     }
                 }
             };
+            // Two slices per trip: 16 weight loads in flight.  A rolling ring of fetches that also runs ahead into the next
+            // layer was tried: with the 256-register budget of two workgroups per CU it spills, and was slower.
             const int kstride = 4 * KPw;
             int kb = kp < KPw ? 4 * kp : in4;                         // lanes beyond the span hold zeros and stay out of the fold
-            if constexpr (NRT <= 6) {                                 // two slices per trip: 16 weight loads in flight
+            if constexpr (NRT <= 6) {
                 for (; kb + kstride < in4; kb += 2 * kstride) {
                     float4 wa[4][2], wb[4][2];
                     kload(kb, wa);
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 const int kind = a.act[l];
                 const float alpha = a.alpha[l];
                 const bool real = tid < out;
-                const float v = s_act[cur][0][tid] + ((real && a.bias[l]) ? a.bias[l][tid] : 0.0f);
+                const float v = s_act[cur][0][tid] + (real ? bias_v : 0.0f);
                 float av = v, d = 1.0f;
                 if (kind == BG_ACT_ELU) {
                     const float e = alpha * expf(v);
@@ -265,11 +269,20 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
             }
             __syncthreads();
         }
-        if (tid < nbar) {
-            s_qs[tid] = (double)s_act[cur][0][tid];
+        // the sweep's coefficient table: modes 0 .. n-1 are the primary ones (coefficient q_p, derivative = identity),
+        // modes n .. n+nbar-1 the closure outputs, the rest (up to a multiple of 8) zero
+        if (tid < m8) {
+            const int j = tid - n;
+            const bool sec = j >= 0 && j < nbar;
+            const double cv = tid < n ? s_q[tid] : (sec ? (double)s_act[cur][0][sec ? j : 0] : 0.0);
+            s_qs[tid] = cv;
 #pragma unroll
-            for (int c = 0; c < ANN_MAX_N; ++c) s_dN[tid][c] = (c < n && 1 + c < NRT) ? (double)s_act[cur][1 + c][tid] : 0.0;
-            if (n <= 5) s_dN[tid][5] = s_qs[tid];                       // [dN_0..4 | N]: three 16-byte reads per mode in the sweep
+            for (int c = 0; c < ANN_MAX_N; ++c) {
+                double dv = 0.0;
+                if (c < n && 1 + c < NRT) dv = tid < n ? (tid == c ? 1.0 : 0.0) : (sec ? (double)s_act[cur][1 + c][sec ? j : 0] : 0.0);
+                s_dN[tid][c] = dv;
+            }
+            if (n <= 5) s_dN[tid][5] = cv;                              // [d_0..4 | coefficient]: three 16-byte reads per mode in the sweep
         }
         __syncthreads();
     };
@@ -286,16 +299,10 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         const int r0 = in0 ? i0 : N - 1, r1 = in1 ? i1 : N - 1;
         double u0v = 0.0, u1v = 0.0, w0[NC], w1[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int cc = c < n ? c : n - 1;
-            const double p0 = a.UpT[(size_t)cc * N + r0], p1 = a.UpT[(size_t)cc * N + r1];
-            const double qc = s_q[c];                                   // zero beyond n
-            w0[c] = c < n ? p0 : 0.0; w1[c] = c < n ? p1 : 0.0;
-            u0v = __builtin_fma(p0, qc, u0v); u1v = __builtin_fma(p1, qc, u1v);
-        }
+        for (int c = 0; c < NC; ++c) { w0[c] = 0.0; w1[c] = 0.0; }
         auto mode = [&](int j, double s0, double s1) {
-            const double qs = NC <= 5 ? s_dN[j][5] : s_qs[j];
-            u0v = __builtin_fma(s0, qs, u0v); u1v = __builtin_fma(s1, qs, u1v);
+            const double cv = NC <= 5 ? s_dN[j][5] : s_qs[j];
+            u0v = __builtin_fma(s0, cv, u0v); u1v = __builtin_fma(s1, cv, u1v);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const double dn = s_dN[j][c];
@@ -303,18 +310,22 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 w1[c] = __builtin_fma(s1, dn, w1[c]);
             }
         };
-        const int nb8 = skip(256) ? 0 : (nbar & ~7);                  // (256: timing builds only)
-        for (int jb = 0; jb < nb8; jb += 8) {
-            double s0[8], s1[8];
+        auto fetch = [&](int jb, double (&s0)[8], double (&s1)[8]) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {                           // 16 loads in flight
-                s0[jj] = a.UsT[(size_t)(jb + jj) * N + r0];
-                s1[jj] = a.UsT[(size_t)(jb + jj) * N + r1];
+            for (int jj = 0; jj < 8; ++jj) {
+                s0[jj] = a.UT[(size_t)(jb + jj) * N + r0];
+                s1[jj] = a.UT[(size_t)(jb + jj) * N + r1];
             }
+        };
+        // eight modes per trip (16 loads in flight); m8 is a multiple of 8.  Prefetching the next eight as well costs 64
+        // more registers in a kernel whose MLP stage already fills the file: measured slower.
+        const int mend = skip(256) ? 0 : m8;                           // (256: timing builds only)
+        for (int jb = 0; jb < mend; jb += 8) {
+            double sa0[8], sa1[8];
+            fetch(jb, sa0, sa1);
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) mode(jb + jj, s0[jj], s1[jj]);
+            for (int jj = 0; jj < 8; ++jj) mode(jb + jj, sa0[jj], sa1[jj]);
         }
-        for (int j = nb8; j < (skip(256) ? 0 : nbar); ++j) mode(j, a.UsT[(size_t)j * N + r0], a.UsT[(size_t)j * N + r1]);
 #pragma unroll
         for (int c = 0; c < RW; ++c) {
             double v0 = 0.0, v1 = 0.0;
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                         }
 #pragma unroll
                         for (int c = 0; c < ANN_MAX_N; ++c)
-                            if (c < n) part[c] = __builtin_fma(a.UpT[(size_t)c * N + i], uc, part[c]);
+                            if (c < n) part[c] = __builtin_fma(a.UT[(size_t)c * N + i], uc, part[c]);
                     }
                     s_g[i] = g;
                 }
@@ -508,8 +519,8 @@ int bg_ann_rom_limits(int* max_n, int* max_nbar, int* max_width, int* max_layers
     return BG_OK;
 }
 
-int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, const double* x, const double* UpT,
-                   const double* UsT, const double* u0, const double* mu1, const double* mu2, int n_layers,
+int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, const double* x, const double* UT,
+                   const double* u0, const double* mu1, const double* mu2, int n_layers,
                    const int* widths, const float* const* wt, const float* const* bias, const int* acts,
                    const float* alphas, double dt, double E, double tol, int max_it, int options, double* hist,
                    int32_t* iters, int32_t* flags, int32_t* info, void* stream)
@@ -529,8 +540,8 @@ int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, co
     }
     for (int l = 0; l <= n_layers; ++l) a.width[l] = widths[l];
     if (B == 0) return BG_OK;
-    if (!x || !UpT || !UsT || !u0 || !mu1 || !mu2 || !hist || !flags || !info || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
-    a.x = x; a.UpT = UpT; a.UsT = UsT; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
+    if (!x || !UT || !u0 || !mu1 || !mu2 || !hist || !flags || !info || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
+    a.x = x; a.UT = UT; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
     a.info = info; a.nl = n_layers; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.B = B; a.n = n; a.nbar = nbar;
     a.nsteps = nsteps; a.max_it = max_it; a.supg = options & BG_OPT_SUPG; a.nonuniform = (options & BG_OPT_NONUNIFORM) ? 1 : 0;
     a.force_pivoted = (options & BG_OPT_FORCE_PIVOTED) ? 1 : 0;

@@ -285,8 +285,9 @@ int bg_mlp_act_jvp(int B, int n1, int h, float *z, const float *bias, int act, f
  *   tangent W = U_p + U_s dN (:1224), the n x n solve (:1237), q_p += dq with err = |dq| / (|q_p| + 1e-14) (:1238-1244),
  *   the closure N(q_p) with its input-Jacobian in one float32 forward-mode pass (the reference evaluates the model in
  *   float32 too), and the decode u = U_p q_p + U_s N(q_p) (:1242).  At the start of a time step q_p = U_p^T u (:1197).
- *   UpT    [n][N]    U_p^T, row-major (columns of U_p contiguous);  n <= 8
- *   UsT    [nbar][N] U_s^T;                                         nbar <= 128, N <= 512
+ *   UT     [m8][N] row-major, m8 = (n + nbar) rounded up to a multiple of 8: rows 0 .. n-1 = U_p^T (the columns of U_p,
+ *          contiguous), rows n .. n+nbar-1 = U_s^T, the rest zero; n <= 8, nbar <= 128, N <= 512.  One array because the
+ *          decode and the tangent are ONE sweep over all n + nbar modes, eight at a time.
  *   the closure, layer l = 0 .. n_layers-1 (n_layers <= 8), all four arrays HOST arrays of length n_layers (widths:
  *   n_layers + 1, widths[0] = n, widths[n_layers] = nbar, every width <= 256):
  *     wt[l]    DEVICE pointer, 16-byte aligned, float32 [in4][ld] row-major = the TRANSPOSE of torch's Linear.weight
@@ -299,8 +300,8 @@ int bg_mlp_act_jvp(int B, int n1, int h, float *z, const float *bias, int act, f
  *   u0, mu1, mu2, hist, iters, flags, info, options and the pivoting rule: as bg_rom_run.
  * --------------------------------------------------------------------------------- */
 int bg_ann_rom_limits(int *max_n, int *max_nbar, int *max_width, int *max_layers);
-int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, const double *x, const double *UpT,
-                   const double *UsT, const double *u0, const double *mu1, const double *mu2, int n_layers,
+int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, const double *x, const double *UT,
+                   const double *u0, const double *mu1, const double *mu2, int n_layers,
                    const int *widths, const float *const *wt, const float *const *bias, const int *acts,
                    const float *alphas, double dt, double E, double tol, int max_it, int options, double *hist,
                    int32_t *iters, int32_t *flags, int32_t *info, void *stream);
