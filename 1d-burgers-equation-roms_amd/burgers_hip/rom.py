@@ -700,7 +700,8 @@ def _ann_fused_plan(model, n, nbar, N, dtype, device):
 def pod_ann_run_fused(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, proj, E=0.0, tol=1e-6, max_it=50, device=None,
                       options=0, plan=None):
     """``pod_ann_prom`` for a batch with the whole time loop on the device (bg_ann_rom_run): one workgroup per sample,
-    the closure MLP evaluated in-kernel in float32.  Returns None when the model is outside what that kernel covers."""
+    the closure MLP evaluated in-kernel in float32, the reduced solve with partial pivoting.  Returns None when the model
+    is outside what that kernel covers."""
     L = _lib.load()
     device = _lib.require_device(device)
     opts = _lib.mesh_options(check_mesh(X), supg=True) | options

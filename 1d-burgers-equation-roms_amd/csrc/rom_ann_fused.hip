@@ -5,7 +5,7 @@
 // workgroup owns a sample for ALL time steps and Gauss-Newton iterations.  Per iteration, with no kernel boundary:
 //     assembly (2 rows per thread)
 //     -> projection of the tangent W = U_p + U_s dN on v_mfma_f64_4x4x4_4b (mfma_pass, as bg_rom_run; W lives in LDS)
-//     -> n x n solve (cooperative guarded Gauss-Jordan, n <= 8)            np.linalg.solve :1237
+//     -> n x n solve with partial pivoting (one wave, n <= 8)              np.linalg.solve :1237
 //     -> q_p += dq, err = |dq| / (|q_p| + 1e-14), stopping test            :1238-1244
 //     -> closure at the new q_p: the MLP value N(q_p) AND its input-Jacobian in ONE forward-mode pass in float32 (the
 //        value and the n tangent directions are the 1 + n rows of a small matrix in LDS; a thread owns 4 outputs of a
@@ -69,10 +69,10 @@ struct AnnRunArgs {
     float alpha[ANN_MAX_LAYERS];
     int nl;
     double dt, E, tol;
-    int N, B, n, nbar, nsteps, max_it, supg, nonuniform, force_pivoted;
+    int N, B, n, nbar, nsteps, max_it, supg, nonuniform;
 };
 
-template <int S, int PROJ, bool PIV>
+template <int S, int PROJ>
 __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
 {
     constexpr int NB = 2;
@@ -83,21 +83,19 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
     __shared__ double s_g[NPAD], s_h[NPAD];
     __shared__ __attribute__((aligned(16))) double s_W[NPAD + 2][RW];      // tangent rows, row i at [i + 1]; zero rows around and beyond N
     __shared__ double s_wtu[4][RW];
-    __shared__ double s_diag[RW], s_y[RW], s_q[RW], s_x[RW];
+    __shared__ double s_q[RW], s_x[RW];
     __shared__ double s_part[4][RW];             // per-wave partial sums of U_p^T u
-    __shared__ int s_bad[4];
     __shared__ int s_info;
     // The two halves of an iteration never overlap in time and share one block of LDS (two workgroups per CU need
-    // <= 80 KB each):  projection + solve: s_coef, s_halo, s_red, s_m   |   closure: s_act, s_dN, s_qs
-    constexpr int kCoefB = NPAD * 4 * 8, kHaloB = 2 * NB * 256 * 8, kRedB = 4 * RW * (RW + 4) * 8, kMB = 2 * 4 * 64 * 8;
+    // <= 80 KB each):  projection + solve: s_coef, s_halo, s_red   |   closure: s_act, s_dN, s_qs
+    constexpr int kCoefB = NPAD * 4 * 8, kHaloB = 2 * NB * 256 * 8, kRedB = 4 * RW * (RW + 4) * 8;
     constexpr int kModes = 128 + ANN_MAX_N;       // secondary + primary modes of the sweep
     constexpr int kActB = 2 * ANN_MAX_ROWS * ANN_MAX_WIDTH * 4, kDnB = kModes * RW * 8, kQsB = kModes * 8;
-    constexpr int kPhaseA = kCoefB + kHaloB + kRedB + kMB, kPhaseB = kActB + kDnB + kQsB;
+    constexpr int kPhaseA = kCoefB + kHaloB + kRedB, kPhaseB = kActB + kDnB + kQsB;
     __shared__ __attribute__((aligned(16))) unsigned char s_shared[kPhaseA > kPhaseB ? kPhaseA : kPhaseB];
     auto& s_coef = *reinterpret_cast<double (*)[NPAD][4]>(s_shared);
     auto& s_halo = *reinterpret_cast<double (*)[2][NB][256]>(s_shared + kCoefB);
     auto& s_red = *reinterpret_cast<double (*)[4][RW][RW + 4]>(s_shared + kCoefB + kHaloB);
-    auto& s_m = *reinterpret_cast<double (*)[2][4][64]>(s_shared + kCoefB + kHaloB + kRedB);
     auto& s_act = *reinterpret_cast<float (*)[2][ANN_MAX_ROWS][ANN_MAX_WIDTH]>(s_shared);   // MLP activations: value row + n tangent rows
     auto& s_dN = *reinterpret_cast<double (*)[kModes][RW]>(s_shared + kActB);               // mode j of the sweep: d(coefficient j)/dq_p, zero beyond n
     auto& s_qs = *reinterpret_cast<double (*)[kModes]>(s_shared + kActB + kDnB);            // coefficient j: q_p, then N(q_p), then zeros
@@ -345,7 +343,6 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
     };
 
     for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
-        if (PIV && !a.force_pivoted && a.info[smp] != BG_INFO_NEEDS_PIVOTING) continue;      // workgroup-uniform
         const double mu1 = a.mu1[smp], mu2 = a.mu2[smp];
         double* hist = a.hist + (size_t)smp * (size_t)(a.nsteps + 1) * (size_t)N;
         __syncthreads();
@@ -381,8 +378,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         __syncthreads();
 
         int flags = 0, info_out = 0;
-        bool aborted = false;
-        for (int step = 0; step < a.nsteps && info_out == 0 && !aborted; ++step) {
+        for (int step = 0; step < a.nsteps && info_out == 0; ++step) {
             // ---- g = M u^n + dt F (:1214) and q_p = U_p^T u^n (:1197) --------------------------------------------------
             {
                 double part[ANN_MAX_N];
@@ -457,19 +453,15 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                     mfma_pass<S, NB, GAL, 0, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
                 __syncthreads();
                 // ---- reduced solve -------------------------------------------------------------------------------
-                double xout = 0.0;
-                if constexpr (PIV) {
-                    if (tid == 0) s_info = 0;
-                    __syncthreads();
-                    if (w == 0) pivoted_solve<NB, GAL>(s_red, s_x, &s_info, lane, n);
-                    __syncthreads();
-                    xout = (lane < RW) ? s_x[lane] : 0.0;
-                    if (s_info != 0 && info_out == 0) info_out = s_info;
-                } else {
-                    bool tripped;
-                    xout = coop_gj_solve<NB, GAL, !skip(2)>(s_red, s_m, s_diag, s_y, s_bad, w, lane, n, tripped);
-                    if (!kTiming && tripped) aborted = true;
-                }
+                // np.linalg.solve's partial-pivoting elimination by wave 0 (n <= 8: 1.5 us).  The guarded pivot-free
+                // elimination of bg_rom_run does not apply here: the columns of U_p + U_s dN are far from orthonormal, the
+                // multipliers exceed 1 in nearly every system, and LAPACK does leave the diagonal.
+                if (tid == 0) s_info = 0;
+                __syncthreads();
+                if (w == 0 && !skip(2)) pivoted_solve<NB, GAL>(s_red, s_x, &s_info, lane, n);
+                __syncthreads();
+                const double xout = (lane < RW) ? s_x[lane] : 0.0;
+                if (s_info != 0 && info_out == 0) info_out = s_info;
                 // ---- q_p += dq, err = |dq| / (|q_p| + 1e-14)  (:1238-1244) -----------------------------------------
                 const double dq = (lane < n) ? xout : 0.0;
                 const double qn = (lane < n) ? s_q[lane] + dq : 0.0;
@@ -478,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 nd = sqrt(nd); nq = sqrt(nq);
                 const double err = nd / (nq + 1e-14);
                 ++k;
-                more = (err > a.tol) && (k < a.max_it) && info_out == 0 && !aborted;
+                more = (err > a.tol) && (k < a.max_it) && info_out == 0;
                 if (kTiming) more = k < 5;
                 if (!(err - err == 0.0)) flags |= BG_FLAG_NONFINITE;
                 if (k >= a.max_it) flags |= BG_FLAG_HIT_CAP;
@@ -492,18 +484,18 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         }
         if (tid == 0) {
             a.flags[smp] = flags;
-            a.info[smp] = aborted ? BG_INFO_NEEDS_PIVOTING : info_out;
+            a.info[smp] = info_out;
         }
     }
 }
 
-template <int S, bool PIV>
+template <int S>
 void launch_ann(int projection, int grid, hipStream_t st, const AnnRunArgs& a)
 {
     if (projection == BG_PROJ_GALERKIN)
-        hipLaunchKernelGGL((rom_ann_fused_kernel<S, BG_PROJ_GALERKIN, PIV>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((rom_ann_fused_kernel<S, BG_PROJ_GALERKIN>), dim3(grid), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((rom_ann_fused_kernel<S, BG_PROJ_LSPG, PIV>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((rom_ann_fused_kernel<S, BG_PROJ_LSPG>), dim3(grid), dim3(256), 0, st, a);
 }
 
 }  // namespace
@@ -544,17 +536,10 @@ int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, co
     a.x = x; a.UT = UT; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
     a.info = info; a.nl = n_layers; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.B = B; a.n = n; a.nbar = nbar;
     a.nsteps = nsteps; a.max_it = max_it; a.supg = options & BG_OPT_SUPG; a.nonuniform = (options & BG_OPT_NONUNIFORM) ? 1 : 0;
-    a.force_pivoted = (options & BG_OPT_FORCE_PIVOTED) ? 1 : 0;
     const int slots = 2 * device_cu_count();         // two workgroups per CU: one's memory latency hides behind the other
     const int grid = B < slots ? B : slots;
     hipStream_t st = (hipStream_t)stream;
-    const bool small = N <= 256;
-    if (!a.force_pivoted) {
-        if (small) launch_ann<4, false>(projection, grid, st, a); else launch_ann<8, false>(projection, grid, st, a);
-        const int rc = check_launch();
-        if (rc != BG_OK) return rc;
-    }
-    launch_ann<8, true>(projection, grid, st, a);       // repair kernel: returns at once unless a sample is marked
+    if (N <= 256) launch_ann<4>(projection, grid, st, a); else launch_ann<8>(projection, grid, st, a);
     return check_launch();
 }
 

@@ -363,6 +363,15 @@ class AnnWorkload(RomWorkload):
         return rom.pod_ann_run(self.X, self.u0, self.mu1d, self.mu2d, a.dt, a.time_steps, self.g["U_p"], self.g["U_s"],
                                self.model, device=self.dev)
 
+    def roofline(self, units, kernel_s):
+        r = super().roofline(units, kernel_s)
+        N, n, nb = self.args.n, 5, 91
+        f32 = 2 * 132000 * (1 + n)
+        r["note"] = ("mixed precision: %.0f %% of the algorithmic flops are the float32 closure (value + input-Jacobian, packed "
+                     "VALU FMAs), the rest fp64 (decode + tangent sweep on the VALU, projection on v_mfma_f64_4x4x4); priced "
+                     "against the fp64 peak like the other ROM configs" % (100.0 * f32 / self.flops_per_step))
+        return r
+
     def describe(self):
         a = self.args
         return ("batched Newton-steps/sec over mu-sweep (sample-Newton-steps/s, intrusive POD-ANN ROM n=5, nbar=91)",

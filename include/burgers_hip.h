@@ -297,7 +297,9 @@ int bg_mlp_act_jvp(int B, int n1, int h, float *z, const float *bias, int act, f
  *     acts[l]  BG_ACT_* applied after layer l, alphas[l] its ELU alpha
  *   limits are reported by bg_ann_rom_limits; a model outside them returns BG_ERR_UNSUPPORTED_R (use the per-iteration
  *   entry points bg_mlp_act_jvp + bg_rom_reduce + bg_lu_solve_update instead).
- *   u0, mu1, mu2, hist, iters, flags, info, options and the pivoting rule: as bg_rom_run.
+ *   u0, mu1, mu2, hist, iters, flags, info: as bg_rom_run; options BG_OPT_SUPG (pod_ann_prom has it) | BG_OPT_NONUNIFORM.
+ *   The n x n solve is np.linalg.solve's elimination with the pivot search, always (one kernel): the columns of
+ *   U_p + U_s dN are far from orthonormal and LAPACK does leave the diagonal on these systems.
  * --------------------------------------------------------------------------------- */
 int bg_ann_rom_limits(int *max_n, int *max_nbar, int *max_width, int *max_layers);
 int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, const double *x, const double *UT,

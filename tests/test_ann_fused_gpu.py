@@ -75,23 +75,6 @@ def test_ann_fused_equals_batched_path_and_oracle(hip, proj):
         assert rel_l2(fh[s].T, Uo) < TOL32 and np.abs(fi[s] - ito).max() <= 1
 
 
-def test_ann_fused_pivoted_branch(hip):
-    """BG_OPT_FORCE_PIVOTED sends every sample through the repair kernel (pivot search of bg_lu_solve): same answer."""
-    from burgers_hip import rom
-    g = load_golden("ann_n5.npz")
-    model = _golden_model(g)
-    X, _ = mesh(512)
-    mu1 = np.linspace(4.3, 5.4, 9); mu2 = np.linspace(0.016, 0.029, 9)
-    for proj in ("galerkin", "lspg"):
-        a = rom.pod_ann_run_fused(X, np.ones(512), mu1, mu2, 0.05, 5, g["U_p"], g["U_s"], model, rom.PROJ[proj])
-        p = rom.pod_ann_run_fused(X, np.ones(512), mu1, mu2, 0.05, 5, g["U_p"], g["U_s"], model, rom.PROJ[proj],
-                                  options=hip.BG_OPT_FORCE_PIVOTED)
-        torch.cuda.synchronize()
-        assert int(p.info.abs().max()) == 0 and int(a.info.abs().max()) == 0
-        assert np.abs(a.iters.cpu().numpy() - p.iters.cpu().numpy()).max() <= 1
-        assert rel_l2(a.hist.cpu().numpy(), p.hist.cpu().numpy()) < 1e-8
-
-
 def _random_mlp(widths, act, bias, seed):
     import torch.nn as nn
     torch.manual_seed(seed)

@@ -173,3 +173,41 @@ def test_local_prom_live_reference():
                                           return_iters=True)
         assert rel_l2(U[:, ::int(g["stride"])], g["U_" + proj]) < 1e-12 and np.array_equal(it, g["iters_" + proj])
         assert len(np.unique(cl)) >= 2                     # the run really switches bases
+
+
+def test_ann_reduced_system_needs_the_pivot_search():
+    """Why bg_ann_rom_run always eliminates with a pivot search (and bg_rom_run does not): on the reference's committed
+    closure the first-iteration reduced systems of pod_ann_prom have sub-diagonal multipliers above 1 in the natural
+    order (LAPACK's getrf leaves the diagonal), while a POD basis gives multipliers far below 1."""
+    g = load_golden("ann_n5.npz")
+    X = np.linspace(0.0, 100.0, 512)
+    Ws = [g[f"W{i}"] for i in range(6)]; bs = [g[f"b{i}"] for i in range(6)]
+    U0 = np.ones(512)
+    M3 = br.mass_tridiag(X); K3 = br.diffusion_tridiag(X)
+    mu1, mu2, At = 4.75, 0.02, 0.05
+    F = br.forcing_vector(X, mu2)
+    C3 = br.convection_tridiag(X, U0)
+    S = br.supg_term(X, U0, mu2)
+    lo, di, up = br.system_tridiag(M3, K3, C3, At, 0.0)
+    b = br.tridiag_matvec(*M3, U0) + At * F - At * S
+    b[0] = mu1
+    R = br.tridiag_matvec(lo, di, up, U0) - b
+
+    def worst_multiplier(A):
+        A = A.copy(); n = len(A); worst = 0.0
+        for k in range(n - 1):
+            m = A[k + 1:, k] / A[k, k]
+            worst = max(worst, np.abs(m).max())
+            A[k + 1:] -= np.outer(m, A[k])
+        return worst
+
+    q_p = g["U_p"].T @ U0
+    dN = br.mlp_jacobian(Ws, bs, q_p.astype(np.float32)).astype(np.float64)
+    W = g["U_p"] + g["U_s"] @ dN
+    for proj in ("lspg", "galerkin"):
+        Ar, _ = br._reduce(lo, di, up, R, W, proj)
+        assert worst_multiplier(Ar) > 1.0, proj
+    Phi = load_golden("committed_pod_r40.npz")["Phi"]
+    for proj in ("lspg", "galerkin"):
+        Ar, _ = br._reduce(lo, di, up, R, Phi, proj)
+        assert worst_multiplier(Ar) < 1.0, proj
