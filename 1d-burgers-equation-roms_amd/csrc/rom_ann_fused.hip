@@ -89,29 +89,39 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
     // The two halves of an iteration never overlap in time and share one block of LDS (two workgroups per CU need
     // <= 80 KB each):  projection + solve: s_coef, s_halo, s_red   |   closure: s_act, s_dN, s_qs
     constexpr int kCoefB = NPAD * 4 * 8, kHaloB = 2 * NB * 256 * 8, kRedB = 4 * RW * (RW + 4) * 8;
-    constexpr int kModes = 128 + ANN_MAX_N;       // secondary + primary modes of the sweep
-    constexpr int kActB = 2 * ANN_MAX_ROWS * ANN_MAX_WIDTH * 4, kDnB = kModes * RW * 8, kQsB = kModes * 8;
+    constexpr int kModes = 128 + ANN_MAX_N + 12;  // secondary + primary modes of the sweep + zero modes that round the trip count up to 3 groups of 4
+    constexpr int kBW = 12;                        // columns of the sweep's right-hand matrix: n derivatives + 1 coefficient, padded to 3 blocks of 4
+    constexpr int kActB = 2 * ANN_MAX_ROWS * ANN_MAX_WIDTH * 4, kDnB = kModes * kBW * 8, kQsB = 0;
     constexpr int kPhaseA = kCoefB + kHaloB + kRedB, kPhaseB = kActB + kDnB + kQsB;
     __shared__ __attribute__((aligned(16))) unsigned char s_shared[kPhaseA > kPhaseB ? kPhaseA : kPhaseB];
     auto& s_coef = *reinterpret_cast<double (*)[NPAD][4]>(s_shared);
     auto& s_halo = *reinterpret_cast<double (*)[2][NB][256]>(s_shared + kCoefB);
     auto& s_red = *reinterpret_cast<double (*)[4][RW][RW + 4]>(s_shared + kCoefB + kHaloB);
     auto& s_act = *reinterpret_cast<float (*)[2][ANN_MAX_ROWS][ANN_MAX_WIDTH]>(s_shared);   // MLP activations: value row + n tangent rows
-    auto& s_dN = *reinterpret_cast<double (*)[kModes][RW]>(s_shared + kActB);               // mode j of the sweep: d(coefficient j)/dq_p, zero beyond n
-    auto& s_qs = *reinterpret_cast<double (*)[kModes]>(s_shared + kActB + kDnB);            // coefficient j: q_p, then N(q_p), then zeros
+    auto& s_dN = *reinterpret_cast<double (*)[kModes][kBW]>(s_shared + kActB);              // mode j of the sweep: [d(coefficient j)/dq_p | coefficient j | 0]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int t = lane & 3, owner = 16 * w + (lane >> 2);
     const int N = a.N, n = a.n, nbar = a.nbar, nr = 1 + a.n, m8 = (a.n + a.nbar + 7) & ~7;
     const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
     const int rowbase = owner * S;
-    const int i0 = tid, i1 = tid + 256;          // the two mesh rows of this thread in the row-wise passes
 
     if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;
     for (int e = tid; e < (NPAD + 2) * RW; e += 256) (&s_W[0][0])[e] = 0.0;
     if (tid < RW) s_q[tid] = 0.0;
 
     // ---- N(q_p) and dN/dq_p at q_p = s_q, float32 forward mode: rows 0 = value, 1 .. n = tangent directions --------
+    long long cyc[14];                           // timing builds only: shader clocks per phase, see the end of the sample loop
+#pragma unroll
+    for (int i = 0; i < 14; ++i) cyc[i] = 0;
+    long long tick = 0;
+    auto lap = [&](int i) {
+        if constexpr (kTiming) {
+            const long long now = (long long)__builtin_amdgcn_s_memtime();
+            cyc[i] += now - tick;
+            tick = now;
+        }
+    };
     // ---- N(q_p) and dN/dq_p at q_p = s_q, float32 forward mode: rows 0 = value, 1 .. n = tangent directions --------
     // Layer l on all 256 threads.  A thread owns 8 outputs (two 16-byte weight loads per input k, no guards: the host
     // pads W^T to [in4][ld]) and every KPw-th group of 4 inputs; lane = (input slice) * P + (output group), so that
@@ -125,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
             for (int r = 1; r < ANN_MAX_ROWS; ++r) s_act[0][r][tid] = (r - 1 == tid && tid < n) ? 1.0f : 0.0f;
         }
         __syncthreads();
+        lap(11);
         for (int l = 0; l < (skip(128) ? 0 : a.nl); ++l) {          // (128: timing builds only)
             const int in4 = (a.width[l] + 3) & ~3, out = a.width[l + 1], ldw = (out + 7) & ~7, ogn = ldw >> 3;
             int P = 1, pshift = 0;
@@ -139,6 +150,10 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
             const int half = 4 * ogn;
             // this thread's bias for the activation stage, fetched now so that its latency hides behind the layer
             const float bias_v = a.bias[l] ? a.bias[l][tid < out ? tid : out - 1] : 0.0f;
+            // ... and the two outputs this lane finishes when the layer takes the swap fold below
+            const int o0 = ((lane >> 4) < 2 ? 4 * og + 2 * (lane >> 4) : half + 4 * og + 2 * ((lane >> 4) - 2));
+            const float bias_0 = a.bias[l] ? a.bias[l][o0 < out ? o0 : out - 1] : 0.0f;
+            const float bias_1 = a.bias[l] ? a.bias[l][o0 + 1 < out ? o0 + 1 : out - 1] : 0.0f;
             float acc[NRT][8];
 #pragma unroll
             for (int r = 0; r < NRT; ++r)
@@ -202,29 +217,55 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
             if (P <= 4 && span > 4) fold([](float v) { return dpp_f32<0x114>(v); });      // row_shr:4
             if (span > 8) fold([](float v) { return dpp_f32<0x118>(v); });                // row_shr:8
             const int half_og = half + 4 * og;
-            if (NRT == 6 && span == 64 && !skip(2048)) {
+            const int kind = a.act[l];
+            const float alpha = a.alpha[l];
+            // bias, activation, derivative scaling: the arithmetic of bg_mlp_act_jvp (csrc/mlp.hip)
+            auto activate = [&](float v, float& av, float& d) {
+                av = v; d = 1.0f;
+                if (kind == BG_ACT_ELU) {
+                    const float e = alpha * expf(v);
+                    av = v > 0.0f ? v : e - alpha;
+                    d = v > 0.0f ? 1.0f : e;
+                } else if (kind == BG_ACT_RELU) {
+                    av = v > 0.0f ? v : 0.0f;
+                    d = v > 0.0f ? 1.0f : 0.0f;
+                } else if (kind == BG_ACT_TANH) {
+                    av = tanhf(v);
+                    d = 1.0f - av * av;
+                }
+            };
+            const bool swapfold = NRT == 6 && span == 64 && !skip(2048);      // workgroup-uniform
+            if (swapfold) {
                 // Across the four rows of 16 lanes with v_permlane16_swap / v_permlane32_swap (VALU; ds_bpermute would make
-                // the LDS pipe the bottleneck): the 12 chunks of 4 outputs (6 rows x 2) are folded four at a time, and
-                // row rho of the wave ends up with the totals of chunk 4 g + rho -- all four rows store.
-                const int rho = lane >> 4;
-                float res[3][4];
+                // the LDS pipe the bottleneck).  One swap + add folds two values, and the pairing is chosen so that row rho of
+                // the wave ends up with the totals of outputs 2 rho, 2 rho + 1 of the thread's eight, for ALL 1 + n rows:
+                // the value and its tangent rows meet in one lane, which applies bias, activation and derivative scaling
+                // in registers -- no second stage, one barrier per layer.
+                float res[6][2];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
+                for (int r = 0; r < 6; ++r) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        // chunk u = 2 r + (first | second half of the row) -> acc[u >> 1][4 (u & 1) + e]
-                        const float s01 = swap16_add(acc[(4 * g) >> 1][e], acc[(4 * g + 1) >> 1][4 + e]);
-                        const float s23 = swap16_add(acc[(4 * g + 2) >> 1][e], acc[(4 * g + 3) >> 1][4 + e]);
-                        res[g][e] = swap32_add(s01, s23);
+                    for (int e = 0; e < 2; ++e) {
+                        const float s01 = swap16_add(acc[r][e], acc[r][2 + e]);
+                        const float s23 = swap16_add(acc[r][4 + e], acc[r][6 + e]);
+                        res[r][e] = swap32_add(s01, s23);
                     }
                 }
                 if ((lane & 15) >= 16 - P && ogr < ogn) {
+                    float outv[6][2];
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        const int u = 4 * g + rho;
-                        *reinterpret_cast<float4*>(&s_act[cur ^ 1][u >> 1][(u & 1) ? half_og : 4 * og]) =
-                            make_float4(res[g][0], res[g][1], res[g][2], res[g][3]);
+                    for (int e = 0; e < 2; ++e) {
+                        const int o = o0 + e;
+                        const bool real = o < out;
+                        float av, d;
+                        activate(res[0][e] + (real ? (e ? bias_1 : bias_0) : 0.0f), av, d);
+                        outv[0][e] = real ? av : 0.0f;                  // the padding outputs feed the next layer's padded inputs
+#pragma unroll
+                        for (int r = 1; r < 6; ++r) outv[r][e] = real ? ((kind != BG_ACT_NONE) ? res[r][e] * d : res[r][e]) : 0.0f;
                     }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+                        *reinterpret_cast<float2*>(&s_act[cur ^ 1][r][o0]) = make_float2(outv[r][0], outv[r][1]);
                 }
             } else {
                 if (span > 16) fold([](float v) { return __shfl_xor(v, 16); });
@@ -240,110 +281,128 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
             }
             __syncthreads();
             cur ^= 1;
-            if (tid < ldw && !skip(4096)) {
-                // bias, activation, derivative scaling, one output per thread: the arithmetic of bg_mlp_act_jvp (csrc/mlp.hip)
-                const int kind = a.act[l];
-                const float alpha = a.alpha[l];
-                const bool real = tid < out;
-                const float v = s_act[cur][0][tid] + (real ? bias_v : 0.0f);
-                float av = v, d = 1.0f;
-                if (kind == BG_ACT_ELU) {
-                    const float e = alpha * expf(v);
-                    av = v > 0.0f ? v : e - alpha;
-                    d = v > 0.0f ? 1.0f : e;
-                } else if (kind == BG_ACT_RELU) {
-                    av = v > 0.0f ? v : 0.0f;
-                    d = v > 0.0f ? 1.0f : 0.0f;
-                } else if (kind == BG_ACT_TANH) {
-                    av = tanhf(v);
-                    d = 1.0f - av * av;
-                }
-                if (!real) { av = 0.0f; d = 0.0f; }                   // the padding outputs feed the next layer's padded inputs
-                s_act[cur][0][tid] = av;
-                if (kind != BG_ACT_NONE || !real) {
+            if (!swapfold) {                                          // second stage, one output per thread
+                if (tid < ldw && !skip(4096)) {
+                    const bool real = tid < out;
+                    float av, d;
+                    activate(s_act[cur][0][tid] + (real ? bias_v : 0.0f), av, d);
+                    if (!real) { av = 0.0f; d = 0.0f; }
+                    s_act[cur][0][tid] = av;
+                    if (kind != BG_ACT_NONE || !real) {
 #pragma unroll
-                    for (int r = 1; r < NRT; ++r) s_act[cur][r][tid] *= d;
+                        for (int r = 1; r < NRT; ++r) s_act[cur][r][tid] *= d;
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
+            if constexpr (kTiming) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i == l) lap(3 + i);
+            }
         }
-        // the sweep's coefficient table: modes 0 .. n-1 are the primary ones (coefficient q_p, derivative = identity),
-        // modes n .. n+nbar-1 the closure outputs, the rest (up to a multiple of 8) zero
-        if (tid < m8) {
+        // the sweep's right-hand matrix: row j = mode j = [d c_j / d q_p (n columns) | c_j | zeros]; modes 0 .. n-1 are the
+        // primary ones (c = q_p, derivative = identity), modes n .. n+nbar-1 the closure outputs, the rest (up to m8) zero
+        if (tid < m8 + 12) {
             const int j = tid - n;
             const bool sec = j >= 0 && j < nbar;
             const double cv = tid < n ? s_q[tid] : (sec ? (double)s_act[cur][0][sec ? j : 0] : 0.0);
-            s_qs[tid] = cv;
 #pragma unroll
-            for (int c = 0; c < ANN_MAX_N; ++c) {
+            for (int c = 0; c < kBW; ++c) {
                 double dv = 0.0;
-                if (c < n && 1 + c < NRT) dv = tid < n ? (tid == c ? 1.0 : 0.0) : (sec ? (double)s_act[cur][1 + c][sec ? j : 0] : 0.0);
+                if (c < ANN_MAX_N && c < n && 1 + c < NRT)
+                    dv = tid < n ? (tid == c ? 1.0 : 0.0) : (sec ? (double)s_act[cur][1 + (c < ANN_MAX_N ? c : 0)][sec ? j : 0] : 0.0);
+                if (c == n) dv = cv;
                 s_dN[tid][c] = dv;
             }
-            if (n <= 5) s_dN[tid][5] = cv;                              // [d_0..4 | coefficient]: three 16-byte reads per mode in the sweep
         }
         __syncthreads();
+        lap(11);
     };
     auto mlp = [&]() __attribute__((always_inline)) {
         if (nr <= 6) mlp_impl(std::integral_constant<int, 6>{});
         else mlp_impl(std::integral_constant<int, ANN_MAX_ROWS>{});
     };
 
-    // ---- one sweep over U_s^T (and U_p^T): tangent W = U_p + U_s dN into s_W, and (decode) u = U_p q_p + U_s N(q_p) ----
-    // Straight-line: NC columns compiled in (dN and q_p are zero beyond n), rows beyond N read row N - 1 and are dropped.
-    auto closure_impl = [&](auto nc_c, bool decode) __attribute__((always_inline)) {
-        constexpr int NC = decltype(nc_c)::value;
-        const bool in0 = i0 < N, in1 = i1 < N;
-        const int r0 = in0 ? i0 : N - 1, r1 = in1 ? i1 : N - 1;
-        double u0v = 0.0, u1v = 0.0, w0[NC], w1[NC];
+    // ---- one sweep over [U_p | U_s]: T = U . B with B = s_dN gives the tangent W = U_p + U_s dN (columns 0 .. n-1, into
+    // s_W) and the decode u = U_p q_p + U_s N(q_p) (column n, into s_u) together, on v_mfma_f64_4x4x4_4b: block = 4 mesh
+    // rows, A = U^T[4 modes][those rows] straight from L2 (one double per lane), B = 4 modes x 4 columns from LDS -- one
+    // 512-byte read per (4 modes, 4 columns) for the whole wave instead of a broadcast 16-byte read per lane, mode and
+    // column pair, which made the LDS pipe the limit of the VALU form of this sweep (2.1 k clocks per 8 modes).
+    auto closure_impl = [&](auto ncb_c, auto full_c, bool decode) __attribute__((always_inline)) {
+        constexpr int NCB = decltype(ncb_c)::value;                            // column blocks compiled in: n derivatives + 1 coefficient
+        constexpr bool FULL = decltype(full_c)::value;                         // N == NPAD: no ragged last lanes
+        const int ak = lane >> 4, ablk = (lane >> 2) & 3, aij = lane & 3;      // A / B operand lane: 16 k + 4 blk + (i | j)
+        const int wrow = 16 * S * w;                                           // first mesh row of this wave
+        // MFMA number tl of a trip works on the rows wrow + S (4 blk + i) + tl: a lane's S rows are consecutive, so its share
+        // of 4 modes x 16 S rows is S / 2 16-byte loads, and 16 neighbouring lanes read 128 S contiguous bytes of a mode
+        const int lrow = wrow + S * (4 * ablk + aij);
+        auto fetch = [&](int kc, double (&dst)[S]) {
+            const double* src = a.UT + (size_t)(4 * kc + ak) * N;
+            if constexpr (FULL) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { w0[c] = 0.0; w1[c] = 0.0; }
-        auto mode = [&](int j, double s0, double s1) {
-            const double cv = NC <= 5 ? s_dN[j][5] : s_qs[j];
-            u0v = __builtin_fma(s0, cv, u0v); u1v = __builtin_fma(s1, cv, u1v);
+                for (int tl = 0; tl < S; tl += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(src + lrow + tl);
+                    dst[tl] = v.x; dst[tl + 1] = v.y;
+                }
+            } else {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const double dn = s_dN[j][c];
-                w0[c] = __builtin_fma(s0, dn, w0[c]);
-                w1[c] = __builtin_fma(s1, dn, w1[c]);
+                for (int tl = 0; tl < S; ++tl) dst[tl] = src[lrow + tl < N ? lrow + tl : N - 1];   // dropped below
             }
         };
-        auto fetch = [&](int jb, double (&s0)[8], double (&s1)[8]) {
+        double acc[S][NCB];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                s0[jj] = a.UT[(size_t)(jb + jj) * N + r0];
-                s1[jj] = a.UT[(size_t)(jb + jj) * N + r1];
-            }
+        for (int tl = 0; tl < S; ++tl)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[tl][cb] = 0.0;
+        auto mma = [&](int kc, const double (&av)[S]) {
+            double bv[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) bv[cb] = s_dN[4 * kc + ak][4 * cb + aij];
+#pragma unroll
+            for (int tl = 0; tl < S; ++tl)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[tl][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[tl], bv[cb], acc[tl][cb], 0, 0, 0);
         };
-        // eight modes per trip (16 loads in flight); m8 is a multiple of 8.  Prefetching the next eight as well costs 64
-        // more registers in a kernel whose MLP stage already fills the file: measured slower.
-        const int mend = skip(256) ? 0 : m8;                           // (256: timing builds only)
-        for (int jb = 0; jb < mend; jb += 8) {
-            double sa0[8], sa1[8];
-            fetch(jb, sa0, sa1);
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) mode(jb + jj, sa0[jj], sa1[jj]);
+        // groups of 4 modes, three buffers: two groups in flight while one is multiplied.  The trip count is rounded up to a
+        // multiple of 3 (the extra groups meet zero rows of B; their fetches are clamped to the last real group): no guards.
+        const int kcn = skip(256) ? 0 : m8 / 4;                                // (256: timing builds only)
+        const int kcl = kcn - 1;
+        double a0[S], a1[S], a2[S];
+        if (kcn > 0) { fetch(0, a0); fetch(1 < kcl ? 1 : kcl, a1); }
+        for (int kc = 0; kc < kcn; kc += 3) {
+            fetch(kc + 2 < kcl ? kc + 2 : kcl, a2);
+            mma(kc, a0);
+            fetch(kc + 3 < kcl ? kc + 3 : kcl, a0);
+            mma(kc + 1, a1);
+            fetch(kc + 4 < kcl ? kc + 4 : kcl, a1);
+            mma(kc + 2, a2);
         }
+        // result lane: 16 i + 4 blk + j holds T[row S (4 blk + i) + tl][column 4 cb + j]
+        const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
 #pragma unroll
-        for (int c = 0; c < RW; ++c) {
-            double v0 = 0.0, v1 = 0.0;
-            if (c < NC) { v0 = w0[c < NC ? c : 0]; v1 = w1[c < NC ? c : 0]; }
-            if (i0 < NPAD) s_W[i0 + 1][c] = in0 ? v0 : 0.0;
-            if (i1 < NPAD) s_W[i1 + 1][c] = in1 ? v1 : 0.0;
-        }
-        if (decode) {
-            if (i0 < NPAD) s_u[i0 + 2] = in0 ? u0v : 0.0;
-            if (i1 < NPAD) s_u[i1 + 2] = in1 ? u1v : 0.0;
+        for (int tl = 0; tl < S; ++tl) {
+            const int row = wrow + S * (4 * dblk + di) + tl;
+            const bool in = row < N;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int col = 4 * cb + dj;
+                const double v = in ? acc[tl][cb] : 0.0;
+                if (col < n) s_W[row + 1][col] = v;
+                if (col == n && decode) s_u[row + 2] = v;
+            }
         }
         __syncthreads();
     };
     auto closure = [&](bool decode) __attribute__((always_inline)) {
-        if (n <= 5) closure_impl(std::integral_constant<int, 5>{}, decode);
-        else closure_impl(std::integral_constant<int, ANN_MAX_N>{}, decode);
+        using T = std::true_type; using F = std::false_type;
+        if (n <= 7) { if (N == NPAD) closure_impl(std::integral_constant<int, 2>{}, T{}, decode); else closure_impl(std::integral_constant<int, 2>{}, F{}, decode); }
+        else { if (N == NPAD) closure_impl(std::integral_constant<int, 3>{}, T{}, decode); else closure_impl(std::integral_constant<int, 3>{}, F{}, decode); }
     };
 
     for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
         const double mu1 = a.mu1[smp], mu2 = a.mu2[smp];
+        if constexpr (kTiming) tick = (long long)__builtin_amdgcn_s_memtime();
         double* hist = a.hist + (size_t)smp * (size_t)(a.nsteps + 1) * (size_t)N;
         __syncthreads();
         // ---- per-sample constants (compute_forcing_vector :427-461, f_gp of :556-558) and the initial state ----------
@@ -419,14 +478,17 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 if (tid < RW) s_q[tid] = (tid < n) ? (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]) : 0.0;
                 __syncthreads();
             }
+            lap(13);
             int k = 0;
             bool more = true, decode = false;
             while (true) {
                 // ---- closure at the current q_p (one call site: the code is inlined once).  First pass of a time step:
                 // dN at the first guess (:1219), tangent only, U0 stays u^n.  Later passes: q_s = N(q_p) for the decode
                 // (:1241-1242) and dN for the next projection (:1219-1224).
+                lap(2);
                 mlp();
                 closure(decode);
+                lap(12);
                 if (!more) break;
                 decode = true;
                 // ---- assembly: A(u_k), R(u_k) per row into LDS ----------------------------------------------------
@@ -449,6 +511,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                     s_halo[1][c][tid] = s_W[rowbase + S + 1][4 * c + t];
                 }
                 __syncthreads();
+                lap(0);
                 if constexpr (!skip(1))
                     mfma_pass<S, NB, GAL, 0, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
                 __syncthreads();
@@ -485,6 +548,12 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         if (tid == 0) {
             a.flags[smp] = flags;
             a.info[smp] = info_out;
+        }
+        if (kTiming && tid == 0 && a.nsteps >= 14) {     // diagnostic builds only: kilo-clocks per phase in place of the counts
+#pragma unroll
+            for (int i = 0; i < 14; ++i) a.iters[(size_t)smp * a.nsteps + i] = (int)(cyc[i] >> 10);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) cyc[i] = 0;
         }
     }
 }
