@@ -234,16 +234,16 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                     d = 1.0f - av * av;
                 }
             };
-            const bool swapfold = NRT == 6 && span == 64 && !skip(2048);      // workgroup-uniform
+            const bool swapfold = (NRT == 6 || NRT == 1) && span == 64 && !skip(2048);      // workgroup-uniform
             if (swapfold) {
                 // Across the four rows of 16 lanes with v_permlane16_swap / v_permlane32_swap (VALU; ds_bpermute would make
                 // the LDS pipe the bottleneck).  One swap + add folds two values, and the pairing is chosen so that row rho of
                 // the wave ends up with the totals of outputs 2 rho, 2 rho + 1 of the thread's eight, for ALL 1 + n rows:
                 // the value and its tangent rows meet in one lane, which applies bias, activation and derivative scaling
                 // in registers -- no second stage, one barrier per layer.
-                float res[6][2];
+                float res[NRT][2];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
+                for (int r = 0; r < NRT; ++r) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const float s01 = swap16_add(acc[r][e], acc[r][2 + e]);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                     }
                 }
                 if ((lane & 15) >= 16 - P && ogr < ogn) {
-                    float outv[6][2];
+                    float outv[NRT][2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int o = o0 + e;
@@ -261,10 +261,10 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                         activate(res[0][e] + (real ? (e ? bias_1 : bias_0) : 0.0f), av, d);
                         outv[0][e] = real ? av : 0.0f;                  // the padding outputs feed the next layer's padded inputs
 #pragma unroll
-                        for (int r = 1; r < 6; ++r) outv[r][e] = real ? ((kind != BG_ACT_NONE) ? res[r][e] * d : res[r][e]) : 0.0f;
+                        for (int r = 1; r < NRT; ++r) outv[r][e] = real ? ((kind != BG_ACT_NONE) ? res[r][e] * d : res[r][e]) : 0.0f;
                     }
 #pragma unroll
-                    for (int r = 0; r < 6; ++r)
+                    for (int r = 0; r < NRT; ++r)
                         *reinterpret_cast<float2*>(&s_act[cur ^ 1][r][o0]) = make_float2(outv[r][0], outv[r][1]);
                 }
             } else {
@@ -319,8 +319,12 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         __syncthreads();
         lap(11);
     };
-    auto mlp = [&]() __attribute__((always_inline)) {
-        if (nr <= 6) mlp_impl(std::integral_constant<int, 6>{});
+    // value_only: the last evaluation of a time step feeds the decode alone (the next step starts from its own first guess,
+    // :1197, :1219), so the n tangent rows -- 5/6 of the layer arithmetic at n = 5 -- are left out; row 0 is computed by the
+    // same operations in the same order either way (same slices, same fold).
+    auto mlp = [&](bool value_only) __attribute__((always_inline)) {
+        if (value_only) mlp_impl(std::integral_constant<int, 1>{});
+        else if (nr <= 6) mlp_impl(std::integral_constant<int, 6>{});
         else mlp_impl(std::integral_constant<int, ANN_MAX_ROWS>{});
     };
 
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 // dN at the first guess (:1219), tangent only, U0 stays u^n.  Later passes: q_s = N(q_p) for the decode
                 // (:1241-1242) and dN for the next projection (:1219-1224).
                 lap(2);
-                mlp();
+                mlp(!more && !kTiming);
                 closure(decode);
                 lap(12);
                 if (!more) break;
