@@ -548,40 +548,73 @@ __global__ __launch_bounds__(256, 1) void rom_reduce4_kernel(ReduceArgs a)
 // ------------------------------------------------------------------------------------
 // quad_tangent_kernel: T[b] = Phi + H3 . q[b]  (reference tangent(), FEM/fem_burgers.py:1120-1123,
 // with H3[i][a][c] = H[i][pair(a,c)] (1 + delta_ac) folding get_dQ_dq :292-312), written straight
-// into the fragment-major layout rom_reduce4_kernel reads.  Workgroup = one (column block c, row
-// slot s): thread (owner = tid>>2, t = tid&3) keeps its H3 row (n doubles) in registers and walks
-// over the samples; q[b][:] is wave-uniform, so it travels through scalar loads and enters the
-// FMAs as SGPR operands.  Memory-bound on the 8 N n bytes per sample it writes.
+// into the fragment-major layout rom_reduce4_kernel reads.  Across the samples this is a GEMM per mesh row,
+// T_i (n x B) = H3_i (n x n) . Q (n x B), and it runs on v_mfma_f64_4x4x4_4b: workgroup = one (column block c, row
+// slot s) and a chunk of 64 samples; MFMA block = one mesh row (owner), A = H3[row][4 columns][4 k] stationary in
+// registers (NKC doubles per lane and owner group), B = q[4 samples][4 k] from the chunk's copy in LDS (one 512-byte read
+// per wave, 4 samples and 4 k -- the first version fed q to VALU FMAs through scalar loads, whose latency it could not hide:
+// 69 us per launch at config 3 against a 21 us arithmetic bound), D = [4 columns][4 samples] per owner, which is 128
+// contiguous bytes of a sample's fragment block per 16 lanes: stored straight from the accumulators.
 // ------------------------------------------------------------------------------------
-template <int S, int NP>
+template <int S, int NKC>
 __global__ __launch_bounds__(256) void quad_tangent_kernel(const double* __restrict__ Phi, const double* __restrict__ H3p,
                                                            const double* __restrict__ qp,
                                                            const int32_t* __restrict__ active, double* __restrict__ Wf,
                                                            int N, int B, int n, int NB, int chunk)
 {
-    // H3p is [N][n][NP] and qp is [B][NP], both zero-padded in their last dimension: no tail tests
-    const int tid = threadIdx.x, owner = tid >> 2, t = tid & 3;
+    // H3p is [N][n][NP] and qp is [B][NP], NP = 4 NKC, both zero-padded in their last dimension: no tail tests
+    constexpr int NP = 4 * NKC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    int* s_on = reinterpret_cast<int*>(s_dyn);                                  // [chunk]
+    double (*s_q)[NP] = reinterpret_cast<double (*)[NP]>(s_dyn + 4 * chunk);    // [chunk][NP]; chunk is a multiple of 4
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = blockIdx.x / S, s = blockIdx.x % S;
-    const int i = owner * S + s, col = 4 * c + t;
-    const bool live = i < N && col < n;
-    double h[NP];
-    const double* hp = H3p + ((size_t)(live ? i : 0) * n + (live ? col : 0)) * NP;
+    const int b0 = blockIdx.y * chunk, nb = min(chunk, B - b0);
+    for (int e = tid; e < chunk * NP; e += 256) {
+        const int sb = e / NP, kk = e - sb * NP;
+        s_q[sb][kk] = sb < nb ? qp[(size_t)(b0 + sb) * NP + kk] : 0.0;
+    }
+    for (int e = tid; e < chunk; e += 256) s_on[e] = (e < nb && (!active || active[b0 + e] != 0)) ? 1 : 0;
+    // A operand lane: 16 k + 4 blk + i, i = column within the block; owner group og: owners 16 w + 4 og + blk
+    const int ak = lane >> 4, ablk = (lane >> 2) & 3, at = lane & 3;
+    double a[4][NKC];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) h[k] = hp[k];
-    const double phi = live ? Phi[(size_t)i * n + col] : 0.0;
-    const size_t per_sample = (size_t)NB * S * 256;
-    const size_t off = ((size_t)(c * S + s) * 64 + owner) * 4 + t;
-    const int b0 = blockIdx.y * chunk, b1 = min(B, b0 + chunk);
-    for (int b = b0; b < b1; ++b) {
-        if (active && active[b] == 0) continue;            // wave-uniform
-        const double* qb = qp + (size_t)b * NP;            // wave-uniform address: scalar loads
-        double acc0 = phi, acc1 = 0.0;
+    for (int og = 0; og < 4; ++og) {
+        const int i = (16 * w + 4 * og + ablk) * S + s, col = 4 * c + at;
+        const bool live = i < N && col < n;
+        const double* hp = H3p + ((size_t)(live ? i : 0) * n + (live ? col : 0)) * NP + ak;
 #pragma unroll
-        for (int k = 0; k < NP; k += 2) {
-            acc0 = __builtin_fma(h[k], qb[k], acc0);
-            acc1 = __builtin_fma(h[k + 1], qb[k + 1], acc1);
+        for (int kc = 0; kc < NKC; ++kc) {
+            const double v = hp[4 * kc];                               // always a valid address: no branch per load
+            a[og][kc] = live ? v : 0.0;
         }
-        Wf[(size_t)b * per_sample + off] = live ? acc0 + acc1 : 0.0;
+    }
+    // result lane: 16 i + 4 blk + j holds T[owner blk][column i][sample j]
+    const int dt = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
+    double phi[4];
+#pragma unroll
+    for (int og = 0; og < 4; ++og) {
+        const int i = (16 * w + 4 * og + dblk) * S + s, col = 4 * c + dt;
+        phi[og] = (i < N && col < n) ? Phi[(size_t)i * n + col] : 0.0;
+    }
+    const size_t per_sample = (size_t)NB * S * 256;
+    const size_t off = ((size_t)(c * S + s) * 64 + 16 * w + dblk) * 4 + dt;      // + 16 og for owner group og
+    __syncthreads();
+    for (int sg = 0; sg < chunk / 4; ++sg) {
+        const int4 on = *reinterpret_cast<const int4*>(&s_on[4 * sg]);
+        if (!(on.x | on.y | on.z | on.w)) continue;        // workgroup-uniform: four converged (or absent) samples
+        double acc[4] = {phi[0], phi[1], phi[2], phi[3]};
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const double bq = s_q[4 * sg + at][4 * kc + ak];          // B operand lane: 16 k + 4 blk + j
+#pragma unroll
+            for (int og = 0; og < 4; ++og) acc[og] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[og][kc], bq, acc[og], 0, 0, 0);
+        }
+        if (s_on[4 * sg + dj]) {
+            double* dst = Wf + (size_t)(b0 + 4 * sg + dj) * per_sample + off;
+#pragma unroll
+            for (int og = 0; og < 4; ++og) dst[16 * og] = acc[og];
+        }
     }
 }
 
@@ -848,22 +881,32 @@ int bg_quad_tangent(int N, int B, int n, const double* Phi, const double* H3, co
     if (n > 40) return BG_ERR_UNSUPPORTED_R;
     if (B == 0) return BG_OK;
     if (!Phi || !H3 || !q || !Wfrag) return BG_ERR_BAD_ARG;
-    const int NB = frag_nb(n), S = frag_s(N), NP = 4 * NB;          // NP: padded last dimension of H3p / qp
-    const int chunk = 64;
+    const int NB = frag_nb(n), S = frag_s(N);                       // 4 NB: padded last dimension of H3p / qp
+    // Samples per workgroup: the kernel runs 4 workgroups per CU (registers), so the sample chunks are sized to give at
+    // most 4 CUs' worth of workgroups -- ONE resident round (64-sample chunks at config 3 made 5 per CU: a second round
+    // with a single workgroup per CU doubled the launch) -- within 32 KB of LDS for the chunk's copy of q.
+    const int slots = 4 * device_cu_count();
+    const int max_chunk = ((32768 / (32 * NB)) / 4) * 4;
+    int nchunks = slots / (NB * S);
+    if (nchunks < 1) nchunks = 1;
+    int chunk = (((B + nchunks - 1) / nchunks) + 3) & ~3;
+    if (chunk < 32) chunk = 32;
+    if (chunk > max_chunk) chunk = max_chunk;
     const dim3 grid(NB * S, (B + chunk - 1) / chunk), block(256);
+    const size_t lds = (size_t)chunk * (4 + 32 * NB);
     hipStream_t st = (hipStream_t)stream;
-#define BG_QT(SV, NPV) hipLaunchKernelGGL((quad_tangent_kernel<SV, NPV>), grid, block, 0, st, Phi, H3, q, active, Wfrag, N, B, n, NB, chunk)
-    switch (S * 100 + NP) {
+#define BG_QT(SV, NKCV) hipLaunchKernelGGL((quad_tangent_kernel<SV, NKCV>), grid, block, lds, st, Phi, H3, q, active, Wfrag, N, B, n, NB, chunk)
+    switch (S * 100 + NB) {
+        case 402: BG_QT(4, 2); break;
+        case 404: BG_QT(4, 4); break;
+        case 406: BG_QT(4, 6); break;
         case 408: BG_QT(4, 8); break;
-        case 416: BG_QT(4, 16); break;
-        case 424: BG_QT(4, 24); break;
-        case 432: BG_QT(4, 32); break;
-        case 440: BG_QT(4, 40); break;
+        case 410: BG_QT(4, 10); break;
+        case 802: BG_QT(8, 2); break;
+        case 804: BG_QT(8, 4); break;
+        case 806: BG_QT(8, 6); break;
         case 808: BG_QT(8, 8); break;
-        case 816: BG_QT(8, 16); break;
-        case 824: BG_QT(8, 24); break;
-        case 832: BG_QT(8, 32); break;
-        case 840: BG_QT(8, 40); break;
+        case 810: BG_QT(8, 10); break;
         default: return BG_ERR_UNSUPPORTED_R;
     }
 #undef BG_QT
