@@ -69,7 +69,7 @@ struct AnnRunArgs {
     float alpha[ANN_MAX_LAYERS];
     int nl;
     double dt, E, tol;
-    int N, B, n, nbar, nsteps, max_it, supg, nonuniform;
+    int N, B, n, nbar, nsteps, max_it, supg, nonuniform, no_reuse;
 };
 
 template <int S, int PROJ>
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
     __shared__ __attribute__((aligned(16))) double s_W[NPAD + 2][RW];      // tangent rows, row i at [i + 1]; zero rows around and beyond N
     __shared__ double s_wtu[4][RW];
     __shared__ double s_q[RW], s_x[RW];
+    __shared__ float s_qlast[RW];                // float32 input of the latest full closure evaluation (see the step start)
     __shared__ double s_part[4][RW];             // per-wave partial sums of U_p^T u
     __shared__ int s_info;
     // The two halves of an iteration never overlap in time and share one block of LDS (two workgroups per CU need
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         int cur = 0;
         if (tid < RW) {                                              // inputs padded with zeros to a multiple of 4
             s_act[0][0][tid] = tid < n ? (float)s_q[tid] : 0.0f;
+            s_qlast[tid] = tid < n ? (float)s_q[tid] : 0.0f;
 #pragma unroll
             for (int r = 1; r < ANN_MAX_ROWS; ++r) s_act[0][r][tid] = (r - 1 == tid && tid < n) ? 1.0f : 0.0f;
         }
@@ -319,9 +321,8 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         __syncthreads();
         lap(11);
     };
-    // value_only: the last evaluation of a time step feeds the decode alone (the next step starts from its own first guess,
-    // :1197, :1219), so the n tangent rows -- 5/6 of the layer arithmetic at n = 5 -- are left out; row 0 is computed by the
-    // same operations in the same order either way (same slices, same fold).
+    // value_only: an evaluation that feeds the decode alone leaves the n tangent rows -- 5/6 of the layer arithmetic at n = 5 --
+    // out; row 0 is computed by the same operations in the same order either way (same slices, same fold).
     auto mlp = [&](bool value_only) __attribute__((always_inline)) {
         if (value_only) mlp_impl(std::integral_constant<int, 1>{});
         else if (nr <= 6) mlp_impl(std::integral_constant<int, 6>{});
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         __syncthreads();
 
         int flags = 0, info_out = 0;
+        bool have_tangent = false;                 // s_W holds U_p + U_s dN at the float32 input s_qlast
         for (int step = 0; step < a.nsteps && info_out == 0; ++step) {
             // ---- g = M u^n + dt F (:1214) and q_p = U_p^T u^n (:1197) --------------------------------------------------
             {
@@ -482,6 +484,13 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 if (tid < RW) s_q[tid] = (tid < n) ? (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]) : 0.0;
                 __syncthreads();
             }
+            // The tangent of the first pass is dN at (float) U_p^T u^n (:1197, :1219).  u^n is the decode of the previous
+            // step's last q_p, so U_p^T u^n is that q_p up to 1e-15 and its float32 image is, as a rule, the very input of the
+            // previous step's last evaluation -- whose tangent is still in s_W.  When the eight floats are bitwise equal the
+            // evaluation would reproduce it bit for bit and is skipped; otherwise (first step, a rounding boundary) it runs.
+            bool skip_eval = have_tangent && !kTiming && !a.no_reuse;
+#pragma unroll
+            for (int c = 0; c < RW; ++c) skip_eval = skip_eval && ((c < n ? (float)s_q[c] : 0.0f) == s_qlast[c]);
             lap(13);
             int k = 0;
             bool more = true, decode = false;
@@ -490,8 +499,14 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 // dN at the first guess (:1219), tangent only, U0 stays u^n.  Later passes: q_s = N(q_p) for the decode
                 // (:1241-1242) and dN for the next projection (:1219-1224).
                 lap(2);
-                mlp(!more && !kTiming);
-                closure(decode);
+                if (!skip_eval) {
+                    // the last evaluation of the last step feeds the decode alone: value only
+                    const bool value_only = !more && step == a.nsteps - 1 && !kTiming;
+                    mlp(value_only);
+                    closure(decode);
+                    have_tangent = !value_only;
+                }
+                skip_eval = false;
                 lap(12);
                 if (!more) break;
                 decode = true;
@@ -609,6 +624,7 @@ int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, co
     a.x = x; a.UT = UT; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
     a.info = info; a.nl = n_layers; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.B = B; a.n = n; a.nbar = nbar;
     a.nsteps = nsteps; a.max_it = max_it; a.supg = options & BG_OPT_SUPG; a.nonuniform = (options & BG_OPT_NONUNIFORM) ? 1 : 0;
+    a.no_reuse = (options & BG_OPT_NO_TANGENT_REUSE) ? 1 : 0;
     const int slots = 2 * device_cu_count();         // two workgroups per CU: one's memory latency hides behind the other
     const int grid = B < slots ? B : slots;
     hipStream_t st = (hipStream_t)stream;

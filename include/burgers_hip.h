@@ -47,7 +47,8 @@ enum { BG_OPT_SUPG = 1,        /* include the SUPG vector (fom_burgers, pod_prom
        BG_OPT_NONUNIFORM = 2,  /* x is not a linspace: use the per-element-length kernels          */
        BG_OPT_W_COLMAJOR = 4,  /* bg_rom_reduce*: W is [r][N] (per sample), not [N][r]             */
        BG_OPT_MFMA_16X16 = 8,  /* bg_rom_reduce*: use the v_mfma_f64_16x16x4 kernel for every r (A/B timing, tests) */
-       BG_OPT_FORCE_PIVOTED = 16 /* bg_rom_run: take the partial-pivoting branch of the reduced solve every time (tests) */ };
+       BG_OPT_FORCE_PIVOTED = 16, /* bg_rom_run: take the partial-pivoting branch of the reduced solve every time (tests) */
+       BG_OPT_NO_TANGENT_REUSE = 32 /* bg_ann_rom_run: evaluate the closure at every step start even when its float32 input is unchanged (tests) */ };
 
 /* transient value of bg_rom_run's info[b] between its two kernels (never seen by the caller) */
 #define BG_INFO_NEEDS_PIVOTING (-1)
@@ -297,7 +298,10 @@ int bg_mlp_act_jvp(int B, int n1, int h, float *z, const float *bias, int act, f
  *     acts[l]  BG_ACT_* applied after layer l, alphas[l] its ELU alpha
  *   limits are reported by bg_ann_rom_limits; a model outside them returns BG_ERR_UNSUPPORTED_R (use the per-iteration
  *   entry points bg_mlp_act_jvp + bg_rom_reduce + bg_lu_solve_update instead).
- *   u0, mu1, mu2, hist, iters, flags, info: as bg_rom_run; options BG_OPT_SUPG (pod_ann_prom has it) | BG_OPT_NONUNIFORM.
+ *   u0, mu1, mu2, hist, iters, flags, info: as bg_rom_run; options BG_OPT_SUPG (pod_ann_prom has it) | BG_OPT_NONUNIFORM |
+ *   BG_OPT_NO_TANGENT_REUSE.  The first-pass tangent of a time step is dN at float32(U_p^T u^n) (:1197, :1219); when those
+ *   floats are bitwise the input of the previous step's last evaluation (the rule: u^n is that step's decode), the tangent is
+ *   still on chip and the evaluation, which would reproduce it bit for bit, is skipped.
  *   The n x n solve is np.linalg.solve's elimination with the pivot search, always (one kernel): the columns of
  *   U_p + U_s dN are far from orthonormal and LAPACK does leave the diagonal on these systems.
  * --------------------------------------------------------------------------------- */

@@ -215,3 +215,22 @@ def test_ann_fused_full_size_cap_pattern(hip):
     assert bool((torch.minimum(f.iters, b.iters).max(dim=1).values[diff] >= 49).all())
     err = (f.hist - b.hist).flatten(1).norm(dim=1) / b.hist.flatten(1).norm(dim=1)
     assert float(err.max()) < TOL32
+
+
+def test_ann_fused_tangent_reuse_is_exact(hip):
+    """At a step start the kernel skips the closure evaluation when float32(U_p^T u^n) is bitwise the input of the previous
+    step's last evaluation (its tangent is still in LDS).  With BG_OPT_NO_TANGENT_REUSE every step start evaluates: the
+    histories, iteration counts and flags must be identical bit for bit."""
+    from burgers_hip import rom
+    g = load_golden("ann_n5.npz")
+    model = _golden_model(g)
+    X, _ = mesh(512)
+    rng = np.random.default_rng(3)
+    B = 520
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    for proj in ("lspg", "galerkin"):
+        a = rom.pod_ann_run_fused(X, np.ones(512), mu1, mu2, 0.05, 12, g["U_p"], g["U_s"], model, rom.PROJ[proj])
+        b = rom.pod_ann_run_fused(X, np.ones(512), mu1, mu2, 0.05, 12, g["U_p"], g["U_s"], model, rom.PROJ[proj],
+                                  options=hip.BG_OPT_NO_TANGENT_REUSE)
+        torch.cuda.synchronize()
+        assert torch.equal(a.hist, b.hist) and torch.equal(a.iters, b.iters) and torch.equal(a.flags, b.flags), proj
