@@ -52,6 +52,55 @@ __device__ __forceinline__ float swap32_add(float a, float b)
     return __builtin_bit_cast(float, (unsigned)t[0]) + __builtin_bit_cast(float, (unsigned)t[1]);
 }
 
+// value of lane `src` (any lane), two ds_bpermute
+__device__ __forceinline__ double lane_f64(double v, int src)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(4 * src, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(4 * src, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// x = solve(Ar, -br) for n <= 8 with np.linalg.solve's pivot choice (the not-yet-used row with the largest |a[k]|, ties
+// to the lowest row, as lu_pivoted_wave), one wavefront, the WHOLE system spread over the lanes: lane 8 i + j holds
+// a[i][j] and a copy of b[i].  Per step: the column entry of the own row and the pivot row's entry of the own column by
+// ds_bpermute, one rank-1 update of all 64 entries; the rows above the pivot are eliminated too (Gauss-Jordan), so what is
+// left is diagonal and there is no back substitution.  lu_pivoted_wave<8> (lane = row, eight serial steps whatever n is,
+// a readlane pair per entry, then eight dependent back-substitution steps) took 10.8 k clocks per call here.
+template <bool GAL>
+__device__ __forceinline__ void pivoted_gj8(const double (*__restrict__ s_red)[8][12], double* __restrict__ s_x,
+                                            int* __restrict__ s_info, int lane, int n)
+{
+    const int i = lane >> 3, j = lane & 7;
+    auto entry = [&](int r, int c) -> double {               // (Ar | br)[r][c], c <= 8; LSPG: mirror the lower blocks
+        int rr = r, cc = c;
+        if (!GAL && c < 8 && (r >> 2) > (c >> 2)) { rr = c; cc = r; }
+        return (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
+    };
+    double A = (i < n && j < n) ? entry(i, j) : (i == j ? 1.0 : 0.0);
+    double rb = (i < n) ? -entry(i, 8) : 0.0;
+    bool used = false;
+    int my_step = -1, info = 0;
+    if (lane < 8) s_x[lane] = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double ck = lane_f64(A, (lane & ~7) | k);                      // a[i][k]
+        const unsigned key = used ? 0u : (((unsigned)__double2hiint(ck) & 0x7fffffffu) + 1u);
+        const unsigned best = wave_max_u32(key);
+        const unsigned long long m = __ballot(key == best && !used);
+        const int p = __builtin_ctzll(m) >> 3;                               // lowest candidate row
+        const double piv = readlane_f64(A, 8 * p + k);
+        if (piv == 0.0 && info == 0) info = k + 1;
+        const double rp = rcp(piv);
+        const double prow = lane_f64(A, 8 * p + j);                          // a[p][j]
+        const double pb = readlane_f64(rb, 8 * p);
+        const double mult = (i == p) ? 0.0 : ck * rp;
+        A = __builtin_fma(-mult, prow, A);
+        rb = __builtin_fma(-mult, pb, rb);
+        if (i == p) { used = true; my_step = k; }
+    }
+    if (j == my_step) s_x[my_step] = rb * rcp(A);                            // the row that pivoted at step k holds x_k
+    if (lane == 0) *s_info = info;
+}
+
 struct AnnRunArgs {
     const double* x;        // [N]
     const double* UT;       // [m8][N]: rows 0 .. n-1 = U_p^T, rows n .. n+nbar-1 = U_s^T, zero rows up to m8 = (n + nbar) rounded up to 8
@@ -534,13 +583,14 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 if constexpr (!skip(1))
                     mfma_pass<S, NB, GAL, 0, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
                 __syncthreads();
+                lap(1);
                 // ---- reduced solve -------------------------------------------------------------------------------
-                // np.linalg.solve's partial-pivoting elimination by wave 0 (n <= 8: 1.5 us).  The guarded pivot-free
+                // np.linalg.solve's partial-pivoting elimination by wave 0 (pivoted_gj8).  The guarded pivot-free
                 // elimination of bg_rom_run does not apply here: the columns of U_p + U_s dN are far from orthonormal, the
                 // multipliers exceed 1 in nearly every system, and LAPACK does leave the diagonal.
                 if (tid == 0) s_info = 0;
                 __syncthreads();
-                if (w == 0 && !skip(2)) pivoted_solve<NB, GAL>(s_red, s_x, &s_info, lane, n);
+                if (w == 0 && !skip(2)) pivoted_gj8<GAL>(s_red, s_x, &s_info, lane, n);
                 __syncthreads();
                 const double xout = (lane < RW) ? s_x[lane] : 0.0;
                 if (s_info != 0 && info_out == 0) info_out = s_info;
