@@ -139,16 +139,18 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
     // The two halves of an iteration never overlap in time and share one block of LDS (two workgroups per CU need
     // <= 80 KB each):  projection + solve: s_coef, s_halo, s_red   |   closure: s_act, s_dN, s_qs
     constexpr int kCoefB = NPAD * 4 * 8, kHaloB = 2 * NB * 256 * 8, kRedB = 4 * RW * (RW + 4) * 8;
-    constexpr int kModes = 128 + ANN_MAX_N + 12;  // secondary + primary modes of the sweep + zero modes that round the trip count up to 3 groups of 4
+    constexpr int kSweepDepth = 3;                 // register buffers of the sweep (groups of 4 modes in flight + 1); 6 measured slower
+    constexpr int kModes = 128 + ANN_MAX_N + 4 * kSweepDepth;   // secondary + primary modes of the sweep + zero modes that round its trip count up
     constexpr int kBW = 12;                        // columns of the sweep's right-hand matrix: n derivatives + 1 coefficient, padded to 3 blocks of 4
-    constexpr int kActB = 2 * ANN_MAX_ROWS * ANN_MAX_WIDTH * 4, kDnB = kModes * kBW * 8, kQsB = 0;
+    constexpr int kBS = 13;                        // its row stride in doubles (odd: the row-per-lane writes spread over the banks)
+    constexpr int kActB = 2 * ANN_MAX_ROWS * ANN_MAX_WIDTH * 4, kDnB = kModes * kBS * 8, kQsB = 0;
     constexpr int kPhaseA = kCoefB + kHaloB + kRedB, kPhaseB = kActB + kDnB + kQsB;
     __shared__ __attribute__((aligned(16))) unsigned char s_shared[kPhaseA > kPhaseB ? kPhaseA : kPhaseB];
     auto& s_coef = *reinterpret_cast<double (*)[NPAD][4]>(s_shared);
     auto& s_halo = *reinterpret_cast<double (*)[2][NB][256]>(s_shared + kCoefB);
     auto& s_red = *reinterpret_cast<double (*)[4][RW][RW + 4]>(s_shared + kCoefB + kHaloB);
     auto& s_act = *reinterpret_cast<float (*)[2][ANN_MAX_ROWS][ANN_MAX_WIDTH]>(s_shared);   // MLP activations: value row + n tangent rows
-    auto& s_dN = *reinterpret_cast<double (*)[kModes][kBW]>(s_shared + kActB);              // mode j of the sweep: [d(coefficient j)/dq_p | coefficient j | 0]
+    auto& s_dN = *reinterpret_cast<double (*)[kModes][kBS]>(s_shared + kActB);              // mode j of the sweep: [d(coefficient j)/dq_p | coefficient j | 0]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int t = lane & 3, owner = 16 * w + (lane >> 2);
@@ -161,9 +163,9 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
     if (tid < RW) s_q[tid] = 0.0;
 
     // ---- N(q_p) and dN/dq_p at q_p = s_q, float32 forward mode: rows 0 = value, 1 .. n = tangent directions --------
-    long long cyc[14];                           // timing builds only: shader clocks per phase, see the end of the sample loop
+    long long cyc[16];                           // timing builds only: shader clocks per phase, see the end of the sample loop
 #pragma unroll
-    for (int i = 0; i < 14; ++i) cyc[i] = 0;
+    for (int i = 0; i < 16; ++i) cyc[i] = 0;
     long long tick = 0;
     auto lap = [&](int i) {
         if constexpr (kTiming) {
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
             for (int r = 1; r < ANN_MAX_ROWS; ++r) s_act[0][r][tid] = (r - 1 == tid && tid < n) ? 1.0f : 0.0f;
         }
         __syncthreads();
-        lap(11);
+        lap(14);
         for (int l = 0; l < (skip(128) ? 0 : a.nl); ++l) {          // (128: timing builds only)
             const int in4 = (a.width[l] + 3) & ~3, out = a.width[l + 1], ldw = (out + 7) & ~7, ogn = ldw >> 3;
             int P = 1, pshift = 0;
@@ -354,16 +356,26 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         }
         // the sweep's right-hand matrix: row j = mode j = [d c_j / d q_p (n columns) | c_j | zeros]; modes 0 .. n-1 are the
         // primary ones (c = q_p, derivative = identity), modes n .. n+nbar-1 the closure outputs, the rest (up to m8) zero
-        if (tid < m8 + 12) {
+        // (all reads unconditional, all choices selects: the branchy form of this table took 4.7 k clocks)
+        if (tid < m8 + 4 * kSweepDepth) {
             const int j = tid - n;
-            const bool sec = j >= 0 && j < nbar;
-            const double cv = tid < n ? s_q[tid] : (sec ? (double)s_act[cur][0][sec ? j : 0] : 0.0);
+            const bool prim = tid < n, sec = j >= 0 && j < nbar;
+            const int jj = sec ? j : 0;
+            float rv[NRT];
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) rv[r] = s_act[cur][r][jj];
+            const double qv = s_q[tid & (RW - 1)];
+            const double cv = prim ? qv : (sec ? (double)rv[0] : 0.0);
 #pragma unroll
             for (int c = 0; c < kBW; ++c) {
                 double dv = 0.0;
-                if (c < ANN_MAX_N && c < n && 1 + c < NRT)
-                    dv = tid < n ? (tid == c ? 1.0 : 0.0) : (sec ? (double)s_act[cur][1 + (c < ANN_MAX_N ? c : 0)][sec ? j : 0] : 0.0);
-                if (c == n) dv = cv;
+                if constexpr (true) {
+                    if (c < ANN_MAX_N && 1 + c < NRT) {                  // compile-time
+                        const double d = prim ? (tid == c ? 1.0 : 0.0) : (sec ? (double)rv[(1 + c < NRT) ? 1 + c : 0] : 0.0);
+                        dv = c < n ? d : 0.0;
+                    }
+                }
+                dv = (c == n) ? cv : dv;
                 s_dN[tid][c] = dv;
             }
         }
@@ -418,19 +430,25 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) acc[tl][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[tl], bv[cb], acc[tl][cb], 0, 0, 0);
         };
-        // groups of 4 modes, three buffers: two groups in flight while one is multiplied.  The trip count is rounded up to a
-        // multiple of 3 (the extra groups meet zero rows of B; their fetches are clamped to the last real group): no guards.
+        // groups of 4 modes, a ring of DEPTH register buffers: DEPTH - 1 groups in flight while one is multiplied.  Three
+        // is enough: the sweep moves 393 KB per evaluation at 24 B/clk per workgroup, with two workgroups on the CU close to
+        // what the 64 B/clk vector-memory return path gives; six buffers measured 7 % slower.  The trip count is rounded up to a multiple of DEPTH (the extra groups meet zero rows of B; their fetches
+        // are clamped to the last real group): no guards anywhere in the loop.
+        constexpr int DEPTH = kSweepDepth;
         const int kcn = skip(256) ? 0 : m8 / 4;                                // (256: timing builds only)
         const int kcl = kcn - 1;
-        double a0[S], a1[S], a2[S];
-        if (kcn > 0) { fetch(0, a0); fetch(1 < kcl ? 1 : kcl, a1); }
-        for (int kc = 0; kc < kcn; kc += 3) {
-            fetch(kc + 2 < kcl ? kc + 2 : kcl, a2);
-            mma(kc, a0);
-            fetch(kc + 3 < kcl ? kc + 3 : kcl, a0);
-            mma(kc + 1, a1);
-            fetch(kc + 4 < kcl ? kc + 4 : kcl, a1);
-            mma(kc + 2, a2);
+        double ab[DEPTH][S];
+        if (kcn > 0) {
+#pragma unroll
+            for (int d = 0; d < DEPTH - 1; ++d) fetch(d < kcl ? d : kcl, ab[d]);
+        }
+        for (int kc = 0; kc < kcn; kc += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int nx = kc + d + DEPTH - 1;
+                fetch(nx < kcl ? nx : kcl, ab[(d + DEPTH - 1) % DEPTH]);
+                mma(kc + d, ab[d]);
+            }
         }
         // result lane: 16 i + 4 blk + j holds T[row S (4 blk + i) + tl][column 4 cb + j]
         const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
@@ -618,11 +636,11 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
             a.flags[smp] = flags;
             a.info[smp] = info_out;
         }
-        if (kTiming && tid == 0 && a.nsteps >= 14) {     // diagnostic builds only: kilo-clocks per phase in place of the counts
+        if (kTiming && tid == 0 && a.nsteps >= 16) {     // diagnostic builds only: kilo-clocks per phase in place of the counts
 #pragma unroll
-            for (int i = 0; i < 14; ++i) a.iters[(size_t)smp * a.nsteps + i] = (int)(cyc[i] >> 10);
+            for (int i = 0; i < 16; ++i) a.iters[(size_t)smp * a.nsteps + i] = (int)(cyc[i] >> 10);
 #pragma unroll
-            for (int i = 0; i < 14; ++i) cyc[i] = 0;
+            for (int i = 0; i < 16; ++i) cyc[i] = 0;
         }
     }
 }

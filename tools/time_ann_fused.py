@@ -28,9 +28,9 @@ for _ in range(3):
     e0.record(); res = run(); e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1))
 timing_build = "abl" in os.environ.get("BG_LIB_PATH", "")
-if timing_build and a.steps >= 14:
-    ph = res.iters[:, :14].double().cpu().numpy() * 1024.0 / (5.0 * a.steps)          # shader clocks per iteration and phase
-    names = ["assembly+fragments", "mfma pass", "solve+update"] + [f"mlp layer {i}" for i in range(8)] + ["mlp head/tail", "sweep", "per-step work"]
+if timing_build and a.steps >= 16:
+    ph = res.iters[:, :16].double().cpu().numpy() * 1024.0 / (5.0 * a.steps)          # shader clocks per iteration and phase
+    names = ["assembly+fragments", "mfma pass", "solve+update"] + [f"mlp layer {i}" for i in range(8)] + ["mlp output table", "sweep", "per-step work", "mlp input set-up", "-"]
     med = np.median(ph, axis=0)
     print("in-kernel shader clocks per iteration (median over samples):")
     for nm, v in zip(names, med):
