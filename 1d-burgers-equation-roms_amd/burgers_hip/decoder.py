@@ -21,26 +21,58 @@ def standardize(Z, mean, std):
     return (Z - mean) / std
 
 
+class GridDecoder:
+    """`predict_on_fom_grid` for batches of (mu1, mu2) with everything that does not depend on the batch kept on the
+    device: the modes in the compute dtype, the standardised time column, the model.  A call is then a handful of
+    launches (the uploads of the 0.65 MB mode matrix and the dtype conversion of the model on every call made the
+    chunked first version of the bench 80 % host time)."""
+
+    def __init__(self, Nt, U_modes, model, mean, std, dtype=torch.float32, device=None):
+        self.device = _lib.require_device(device)
+        self.dtype, self.Nt = dtype, int(Nt)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        mean = torch.as_tensor(np.asarray(mean, dtype=np.float64), **f64).reshape(3)
+        std = torch.as_tensor(np.asarray(std, dtype=np.float64), **f64).reshape(3).clone()
+        std[std == 0] = 1.0
+        self.mean, self.std = mean, std
+        tau = torch.linspace(0.0, 1.0, self.Nt, **f64)
+        self.z_tau = ((tau - mean[2]) / std[2])                              # (Nt,)
+        self.model = model.to(device=self.device, dtype=dtype).eval()
+        Um = torch.as_tensor(np.asarray(U_modes), device=self.device) if not torch.is_tensor(U_modes) else U_modes.to(self.device)
+        # reference: float64 modes @ float32 MLP output; bf16 tier: low-precision GEMM with fp32 accumulate
+        self.Um = Um.to(torch.float64 if dtype == torch.float32 else dtype).contiguous()
+
+    def predict(self, mu1, mu2):
+        """(B, N, Nt) float64 on the device, sample b = (mu1[b], mu2[b])."""
+        f64 = dict(dtype=torch.float64, device=self.device)
+        mu1 = torch.as_tensor(mu1, **f64).reshape(-1)
+        mu2 = torch.as_tensor(mu2, **f64).reshape(-1)
+        B = max(mu1.numel(), mu2.numel())
+        z1 = ((mu1 - self.mean[0]) / self.std[0]).expand(B)
+        z2 = ((mu2 - self.mean[1]) / self.std[1]).expand(B)
+        Zs = torch.stack([z1[:, None].expand(B, self.Nt), z2[:, None].expand(B, self.Nt),
+                          self.z_tau[None, :].expand(B, self.Nt)], dim=-1).reshape(B * self.Nt, 3)
+        with torch.no_grad():
+            Q = self.model(Zs.to(self.dtype)).reshape(B, self.Nt, -1)                  # (B, Nt, n)
+            # Uhat[b] = U_modes @ Q[b]^T as ONE batched product that lands directly in the (B, N, Nt) result layout
+            # (a (N, B*Nt) product followed by permute + contiguous moves the 8-byte result twice more)
+            if self.dtype == torch.float32:
+                return torch.matmul(self.Um, Q.to(torch.float64).transpose(1, 2))
+            N, n = self.Um.shape
+            if self.dtype == torch.bfloat16 and N % 32 == 0 and n % 16 == 0 and n <= 256:
+                # bf16 tier: the product is write-bound; bg_decode_modes_bf16 writes the float64 result once instead of a
+                # bf16 GEMM result plus a cast pass over it
+                Qc = Q.reshape(B * self.Nt, n).contiguous()
+                out = torch.empty((B, N, self.Nt), dtype=torch.float64, device=self.device)
+                with torch.cuda.device(self.device):
+                    _lib.check(_lib.load().bg_decode_modes_bf16(N, n, B, self.Nt, _lib.ptr(self.Um), _lib.ptr(Qc), _lib.ptr(out),
+                                                                _lib.stream_ptr(self.device)), "bg_decode_modes_bf16")
+                return out
+            return torch.matmul(self.Um, Q.transpose(1, 2)).to(torch.float64)
+
+
 def predict_on_grid(mu1, mu2, Nt, U_modes, model, mean, std, dtype=torch.float32, device=None):
     """Batched decoder: returns (B, N, Nt) float64 on the device, sample b = (mu1[b], mu2[b])."""
-    device = _lib.require_device(device)
-    mu1 = torch.as_tensor(np.atleast_1d(np.asarray(mu1, dtype=np.float64)), device=device)
-    mu2 = torch.as_tensor(np.atleast_1d(np.asarray(mu2, dtype=np.float64)), device=device)
-    B = max(mu1.numel(), mu2.numel())
-    mu1, mu2 = mu1.expand(B), mu2.expand(B)
-    tau = torch.linspace(0.0, 1.0, Nt, dtype=torch.float64, device=device)
-    Z = torch.stack([mu1[:, None].expand(B, Nt), mu2[:, None].expand(B, Nt), tau[None, :].expand(B, Nt)], dim=-1)
-    mean = torch.as_tensor(np.asarray(mean, dtype=np.float64), device=device).reshape(1, 1, 3)
-    std = torch.as_tensor(np.asarray(std, dtype=np.float64), device=device).reshape(1, 1, 3)
-    Zs = standardize(Z, mean, std).reshape(B * Nt, 3)
-    model = model.to(device=device, dtype=dtype)
-    Um = torch.as_tensor(np.asarray(U_modes), device=device)
-    with torch.no_grad():
-        Q = model(Zs.to(dtype)).reshape(B, Nt, -1)                 # (B, Nt, n)
-        # Uhat[b] = U_modes @ Q[b]^T as ONE batched product that lands directly in the (B, N, Nt) result layout
-        # (a (N, B*Nt) product followed by permute + contiguous moves the 8-byte result twice more)
-        if dtype == torch.float32:
-            U = torch.matmul(Um.to(torch.float64), Q.to(torch.float64).transpose(1, 2))     # reference: float64 modes @ float32 output
-        else:
-            U = torch.matmul(Um.to(dtype), Q.transpose(1, 2)).to(torch.float64)             # bf16 tier: low-precision GEMM, fp32 accumulate
-    return U
+    mu1 = np.atleast_1d(np.asarray(mu1, dtype=np.float64)) if not torch.is_tensor(mu1) else mu1
+    mu2 = np.atleast_1d(np.asarray(mu2, dtype=np.float64)) if not torch.is_tensor(mu2) else mu2
+    return GridDecoder(Nt, U_modes, model, mean, std, dtype=dtype, device=device).predict(mu1, mu2)

@@ -312,6 +312,14 @@ int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, co
                    const float *alphas, double dt, double E, double tol, int max_it, int options, double *hist,
                    int32_t *iters, int32_t *flags, int32_t *info, void *stream);
 
+/* bg_decode_modes_bf16 -- the contraction of the non-intrusive POD-ANN decoder (bf16 tier of BASELINE config 5)
+ *   reference: `Uhat = U_modes @ Qhat.T`, Non-Instrusive/predict_pod_ann.py:73-80, for a batch of (mu1, mu2) samples
+ *   out[b][i][t] = sum_k Um[i][k] * Q[b * Nt + t][k]: bf16 operands, float32 accumulate, each result written once as
+ *   float64 in the (N, Nt) C-order snapshot layout per sample.
+ *   Um  [N][n] bf16 (raw 16-bit patterns), Q [B * Nt][n] bf16 (the MLP output), both 16-byte aligned; out [B][N][Nt]
+ *   N a multiple of 32, n a multiple of 16, n <= 256 (BG_ERR_UNSUPPORTED_N / _R otherwise: use a library GEMM). */
+int bg_decode_modes_bf16(int N, int n, int B, int Nt, const uint16_t *Um, const uint16_t *Q, double *out, void *stream);
+
 /* bg_jacobi_sweep -- n_steps steps of a one-sided (Hestenes) Jacobi SVD sweep, the accurate small core of
  * the snapshot SVD (reference: np.linalg.svd at POD/pod.py:84, build_quadratic_manifold.py:29).
  *   G      [m][ld] row-major: the m rows are orthogonalised in place by plane rotations

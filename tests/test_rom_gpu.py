@@ -1,6 +1,8 @@
 """GPU parity of the projection-ROM path (bg_rom_reduce, bg_lu_solve and the three batched
 time-steppers) against the oracle and the golden fixtures.  fp64 parts: rel-L2 <= 1e-10;
 POD-ANN is fp32-limited by the reference's own float32 MLP evaluation."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -622,3 +624,26 @@ def test_closure_roms_cap_pattern_matches_the_oracle(hip):
     for b in range(4):
         Uo, ito = br.pod_rbf_prom(X, 0.05, nT, np.ones(512), mu1[b], 0.0, mu2[b], *cl, return_iters=True)
         assert np.array_equal(res.iters[b].cpu().numpy(), ito) and rel_l2(res.hist[b].cpu().numpy().T, Uo) < 1e-9
+
+
+@pytest.mark.parametrize("N,n,B,Nt", [(512, 160, 5, 501), (64, 16, 3, 7), (96, 256, 2, 130), (512, 160, 1, 1), (32, 48, 300, 3)])
+def test_decode_modes_bf16_kernel(hip, N, n, B, Nt):
+    """bg_decode_modes_bf16 (bf16 MFMA, float32 accumulate, float64 result in the (B, N, Nt) snapshot layout) against the
+    same product of the bf16-rounded operands in float64: columns that straddle samples, a ragged last workgroup, every
+    k-block count class; then the refusals."""
+    from burgers_hip import lib as L_
+    L = L_.load()
+    g = torch.Generator(device="cuda").manual_seed(N + n)
+    Um = torch.randn((N, n), device="cuda", generator=g).to(torch.bfloat16)
+    Q = torch.randn((B * Nt, n), device="cuda", generator=g).to(torch.bfloat16)
+    out = torch.full((B, N, Nt), -7.0, dtype=torch.float64, device="cuda")
+    L_.check(L.bg_decode_modes_bf16(N, n, B, Nt, L_.ptr(Um), L_.ptr(Q), L_.ptr(out), L_.stream_ptr(torch.device("cuda", 0))),
+             "bg_decode_modes_bf16")
+    torch.cuda.synchronize()
+    ref = torch.matmul(Um.double(), Q.double().reshape(B, Nt, n).transpose(1, 2))
+    assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max())          # float32 accumulation over n terms
+    z = ctypes.c_void_p(0)
+    assert L.bg_decode_modes_bf16(33, 16, 1, 1, z, z, z, z) == hip.BG_ERR_UNSUPPORTED_N
+    assert L.bg_decode_modes_bf16(32, 20, 1, 1, z, z, z, z) == hip.BG_ERR_UNSUPPORTED_R
+    assert L.bg_decode_modes_bf16(32, 16, 1, 1, z, z, z, z) == hip.BG_ERR_BAD_ARG
+    assert L.bg_decode_modes_bf16(32, 16, 0, 1, z, z, z, z) == hip.BG_OK
