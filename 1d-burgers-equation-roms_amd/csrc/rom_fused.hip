@@ -122,6 +122,15 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
         }
         __syncthreads();
 
+        long long cyc[6] = {0, 0, 0, 0, 0, 0};          // timing builds only: shader clocks per phase
+        long long tick = kTiming ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        auto lap = [&](int i) {
+            if constexpr (kTiming) {
+                const long long now = (long long)__builtin_amdgcn_s_memtime();
+                cyc[i] += now - tick;
+                tick = now;
+            }
+        };
         const long long stamp0 = kTiming ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const long long real0 = kTiming ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
         int flags = 0, info_out = 0;
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
             }
             int k = 0;
             bool more;
+            lap(5);
             do {
                 // ---- assembly: A(u_k), R(u_k) per row into LDS ----------------------------------------------------
                 if (!skip(16))
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                     s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = R;
                 }
                 __syncthreads();
+                lap(0);
                 // ---- projection on the matrix cores -----------------------------------------------------------------
                 // Galerkin: two passes over the rows with half of the (NB + 1) NB accumulators live in each (one pass spills at
                 // r = 40); LSPG: its NB (NB + 1) / 2 + 2 NB accumulators fit one pass, which forms the operands once.
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                     mfma_pass<S, NB, GAL, CM, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
                 }
                 __syncthreads();
+                lap(1);
                 // ---- reduced solve: load own columns (sum of the four waves' partials), eliminate ----------------
                 auto entry = [&](int i, int j) -> double {               // (Ar | br | wtu)[i][j], j <= RW + 1
                     int rr = i, cc = j;
@@ -193,6 +205,7 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                     xout = coop_gj_solve<NB, GAL, !skip(2)>(s_red, s_m, s_diag, s_y, s_bad, w, lane, r, tripped);
                     if (!kTiming && tripped) aborted = true;
                 }
+                lap(2);
                 // ---- q = Phi^T u_k + dq, err = |dq| / |q|  (:770-776) ---------------------------------------------
                 double wtu = 0.0;
                 if (lane < r) {
@@ -212,6 +225,7 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                 if (k >= a.max_it) flags |= BG_FLAG_HIT_CAP;
                 if (w == 0 && lane < RW) s_q[lane] = qn;
                 __syncthreads();
+                lap(3);
                 // ---- lift u_{k+1} = Phi q from the register-resident basis (:773) --------------------------------
                 if (!skip(8)) {
                     double qv[NB];
@@ -231,6 +245,7 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                     }
                 }
                 __syncthreads();
+                lap(4);
             } while (more);
             // ---- U[:, n+1] = U1 (:779): one coalesced row ----------------------------------------------------------
             double* hrow = hist + (size_t)(step + 1) * N;
@@ -243,6 +258,8 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
             if (kTiming && a.nsteps >= 2) {      // diagnostic builds only: shader cycles and 100 MHz ticks of this sample, in kilo-units
                 a.iters[(size_t)smp * a.nsteps] = (int)(((long long)__builtin_amdgcn_s_memtime() - stamp0) >> 10);
                 a.iters[(size_t)smp * a.nsteps + 1] = (int)(((long long)__builtin_amdgcn_s_memrealtime() - real0) >> 10);
+                if (a.nsteps >= 8)
+                    for (int i = 0; i < 6; ++i) a.iters[(size_t)smp * a.nsteps + 2 + i] = (int)(cyc[i] >> 10);
             }
         }
     }

@@ -32,6 +32,11 @@ for _ in range(3):
 timing_build = "abl" in os.environ.get("BG_LIB_PATH", "")
 if timing_build:
     st = res.iters[:, :2].double().cpu().numpy(); clk = np.median(st[:, 0] / st[:, 1]) * 100.0
+    if a.steps >= 8:
+        ph = np.median(res.iters[:, 2:8].double().cpu().numpy(), axis=0) * 1024.0 / (5.0 * a.steps)
+        print("in-kernel shader clocks per iteration (median over samples): " +
+              ", ".join(f"{nm} {v:.0f}" for nm, v in zip(["assembly", "mfma", "solve", "update", "lift", "per-step"], ph)) + f", total {ph.sum():.0f}")
+    res.iters[:, :8] = 5
     res.iters[:, :2] = 5
 its = int(res.iters.sum().item())
 cus = torch.cuda.get_device_properties(0).multi_processor_count
