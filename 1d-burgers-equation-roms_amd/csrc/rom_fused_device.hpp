@@ -20,20 +20,22 @@ constexpr bool kTiming = kAblate >= 0;
 constexpr bool skip(int bit) { return kTiming && (kAblate & bit) != 0; }
 
 
-// ---- one MFMA pass over this wave's rows: pairs (ca, cb) with ca in [CA0, CA1) ---------------------------------
+// ---- one MFMA pass over this wave's rows: pairs (ca, cb) with ca in [CA0, CA1) (LSPG) / cb in [CA0, CA1) (Galerkin) ----
 // Same operand layout, accumulation order and block-partial summation as rom_reduce4_kernel (rom.hip), so the
 // reduced system has the bits of the batched path.  frag[c][s] = Phi[rowbase + s][4 c + t]; the two halo rows
 // Phi[rowbase - 1], Phi[rowbase + S] of every column block sit in LDS (s_halo[0 / 1][c][tid], one private slot per
 // thread: conflict-free 8-byte reads) and are fetched when the first / last row step needs them -- 40 VGPRs fewer
-// live across the whole kernel.  LAST: this pass also carries the Phi^T u accumulators of the LSPG form.
+// live across the whole kernel.  LAST: this pass also carries the Phi^T u accumulators of the LSPG form / the [R, u]
+// column of the Galerkin form.  The Galerkin passes split the B side (cb): a pass forms only the (A Phi) operands of its own
+// column blocks, so two passes form every operand once (a split of the A side formed all of them twice: 240 instructions).
 template <int S, int NB, bool GAL, int CA0, int CA1, bool LAST, int RW>
 __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const double (*__restrict__ s_halo)[NB][256],
                                           const double (*__restrict__ s_coef)[4], const double* __restrict__ s_u,
                                           int rowbase, int t, int w, int lane, int tid,
                                           double (*__restrict__ s_red)[RW][RW + 4], double (*__restrict__ s_wtu)[RW])
 {
-    constexpr int NROW = GAL ? (CA1 - CA0) * (NB + 1) : (CA1 - CA0) * (2 * NB - CA0 - CA1 + 1) / 2 + (CA1 - CA0);
-    constexpr int NACC = NROW + ((!GAL && LAST) ? NB : 0);
+    constexpr int NROW = GAL ? (CA1 - CA0) * NB : (CA1 - CA0) * (2 * NB - CA0 - CA1 + 1) / 2 + (CA1 - CA0);
+    constexpr int NACC = NROW + (LAST ? NB : 0);
     double acc[NACC];
 #pragma unroll
     for (int p = 0; p < NACC; ++p) acc[p] = 0.0;
@@ -43,7 +45,7 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const dou
         const double lo = s_coef[i][0], di = s_coef[i][1], up = s_coef[i][2], R = s_coef[i][3];
         const double ui = s_u[i + 2];
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {
+        for (int c = (GAL ? CA0 : 0); c < (GAL ? CA1 : NB); ++c) {
             const double below = (s == 0) ? s_halo[0][c][tid] : frag[c][s == 0 ? 0 : s - 1];
             const double above = (s == S - 1) ? s_halo[1][c][tid] : frag[c][s == S - 1 ? s : s + 1];
             double y = lo * below;
@@ -63,12 +65,15 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const dou
         int p = 0;
         if constexpr (GAL) {
 #pragma unroll
-            for (int ca = CA0; ca < CA1; ++ca) {
+            for (int ca = 0; ca < NB; ++ca) {
 #pragma unroll
-                for (int cb = 0; cb < NB; ++cb, ++p)
+                for (int cb = CA0; cb < CA1; ++cb, ++p)
                     acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], Y[cb], acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], X, acc[p], 0, 0, 0);
-                ++p;
+            }
+            if constexpr (LAST) {
+#pragma unroll
+                for (int ca = 0; ca < NB; ++ca, ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], X, acc[p], 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -98,10 +103,32 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const dou
         if (writer) s_red[w][oi][oj] = v;
         return;
     }
+    if constexpr (GAL) {
+#pragma unroll
+        for (int ca = 0; ca < NB; ++ca) {
+#pragma unroll
+            for (int cb = CA0; cb < CA1; ++cb, ++p) {
+                double v = acc[p];
+                v += dpp_mov<0x114>(v);          // row_shr:4
+                v += dpp_mov<0x118>(v);          // row_shr:8 -> lanes with blk == 3 hold the sum
+                if (writer) s_red[w][4 * ca + oi][4 * cb + oj] = v;
+            }
+        }
+        if constexpr (LAST) {
+#pragma unroll
+            for (int ca = 0; ca < NB; ++ca, ++p) {
+                double v = acc[p];
+                v += dpp_mov<0x114>(v);
+                v += dpp_mov<0x118>(v);
+                if (writer) s_red[w][4 * ca + oi][4 * NB + oj] = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ca = CA0; ca < CA1; ++ca) {
 #pragma unroll
-        for (int cb = (GAL ? 0 : ca); cb <= NB; ++cb, ++p) {
+        for (int cb = ca; cb <= NB; ++cb, ++p) {
             double v = acc[p];
             v += dpp_mov<0x114>(v);          // row_shr:4
             v += dpp_mov<0x118>(v);          // row_shr:8 -> lanes with blk == 3 hold the sum
