@@ -196,6 +196,7 @@ def _fd_run_fd_jacobian(a, b, N, u0d, mu1d, mu2d, dt, nsteps, max_iter, tol, dev
     for step in range(nsteps):
         Up, Ug = Uc.clone(), Uc.clone()
         active = torch.ones((B,), dtype=torch.bool, device=device)
+        singular = torch.zeros((B,), dtype=torch.bool, device=device)
         k = torch.zeros((B,), dtype=torch.int32, device=device)
         for _ in range(max_iter):
             Ug = torch.where(active[:, None], bc(Ug), Ug)
@@ -203,15 +204,24 @@ def _fd_run_fd_jacobian(a, b, N, u0d, mu1d, mu2d, dt, nsteps, max_iter, tol, dev
             active = active & ~(R[:, 1:-1].abs().amax(dim=1) < tol)          # "Converged." on the residual (:77)
             if not bool(active.any()):
                 break
-            Rp = _fd_residual(Ug[:, None, :] + eye[None], Up[:, None, :], dt, dx, s_src[:, None, :])   # (B, N-2, N)
-            J = ((Rp[:, :, 1:N - 1] - R[:, None, 1:N - 1]) / 1e-8).transpose(1, 2)                   # J[i, j] = dR_i/dU_j
-            dU = torch.zeros_like(Ug)
-            dU[:, 1:-1] = torch.linalg.solve(J, -R[:, 1:-1].unsqueeze(-1)).squeeze(-1)
-            rel = dU[:, 1:-1].abs().amax(dim=1) / Ug[:, 1:-1].abs().amax(dim=1).clamp_min(1e-15)
-            Ug = torch.where(active[:, None], Ug + dU, Ug)
-            k += active.to(torch.int32)
-            active = active & ~(rel < tol)
-        flags |= active.to(torch.int32) * _lib.BG_FLAG_HIT_CAP                # "did not converge within max_iter" (:97)
+            # only the samples still iterating pay for a dense Jacobian and its (N-2)^3 solve
+            ia = active.nonzero().squeeze(1)
+            Ua, Upa, Ra, sa = Ug[ia], Up[ia], R[ia], s_src[ia]
+            Rp = _fd_residual(Ua[:, None, :] + eye[None], Upa[:, None, :], dt, dx, sa[:, None, :])     # (Ba, N-2, N)
+            J = ((Rp[:, :, 1:N - 1] - Ra[:, None, 1:N - 1]) / 1e-8).transpose(1, 2)                  # J[i, j] = dR_i/dU_j
+            sol, info = torch.linalg.solve_ex(J, -Ra[:, 1:-1].unsqueeze(-1), check_errors=False)
+            # "Jacobian is singular" (:88-93): that sample leaves its Newton loop with U_guess as it stands, no update
+            # and no count for this iteration; the others go on
+            good = info == 0
+            ig = ia[good]
+            dU = torch.zeros_like(Ua)
+            dU[:, 1:-1] = sol.squeeze(-1)
+            rel = dU[:, 1:-1].abs().amax(dim=1) / Ua[:, 1:-1].abs().amax(dim=1).clamp_min(1e-15)
+            Ug[ig] = (Ua + dU)[good]
+            k[ig] += 1
+            active[ia] = good & ~(rel < tol)
+            singular[ia[~good]] = True
+        flags |= (active & ~singular).to(torch.int32) * _lib.BG_FLAG_HIT_CAP  # "did not converge within max_iter" (:97)
         iters[:, step] = k
         Uc = bc(Ug)
         hist[:, step + 1] = Uc

@@ -165,7 +165,12 @@ def check(code, where):
 def require_device(device=None):
     if not torch.cuda.is_available():
         raise RuntimeError("no HIP device visible: the Burgers HIP kernels need an MI355X (no CPU fallback)")
-    return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:      # 'cuda' -> 'cuda:<current>': tensors report an indexed device
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
 
 
 def ptr(t):

@@ -12,6 +12,7 @@ skipped by the kernels, so every sample follows exactly the reference's own loop
 """
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -538,6 +539,8 @@ class AnnEvaluator:
     to torch.func (vmap of jacfwd), the batched stand-in for the reference's per-sample
     torch.autograd.functional.jacobian (:1254-1275)."""
 
+    _live = weakref.WeakSet()         # evaluators that currently own a captured graph
+
     def __init__(self, model, n, dtype):
         self.model, self.dtype = model, dtype
         self.layers = _mlp_layers(model)
@@ -593,16 +596,27 @@ class AnnEvaluator:
             self.jt_out.copy_(x[:, 1:, :])
 
         self._run = run
+        self._device = device
+        import os
+        if os.environ.get("BG_ANN_GRAPH", "1") == "0":        # eager launches: the capture is an optimisation only
+            return
+        # Graph lifetime is explicit ("AnnEvaluator graph lifetime"): no captured graph of an OLDER
+        # evaluator is alive -- or still replaying -- while a new capture runs, and none is left to the garbage
+        # collector, which may run at any point, also inside someone else's capture.
+        for other in list(AnnEvaluator._live):
+            if other is not self:
+                other.release()
         try:
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):                      # warm-up outside capture (lazy inits, GEMM selection)
                 run(); run()
             torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
             g = torch.cuda.CUDAGraph()
             import gc
             was_enabled = gc.isenabled()
-            gc.disable()           # a collection DURING capture may destroy an older evaluator's graph: the runtime aborts
+            gc.disable()           # no finaliser (of anything holding device memory or a graph) runs inside the capture
             try:
                 with torch.cuda.graph(g):
                     run()
@@ -610,12 +624,17 @@ class AnnEvaluator:
                 if was_enabled:
                     gc.enable()
             self._graph = g
+            AnnEvaluator._live.add(self)
         except Exception:                                      # capture is an optimisation only
             self._graph = None
 
     def release(self):
-        """Drop the captured graph now (outside any capture) instead of whenever the collector gets to it."""
-        self._graph = None
+        """Destroy the captured graph NOW: after the device has finished every replay of it, outside any capture --
+        not whenever the collector gets to it."""
+        if getattr(self, "_graph", None) is not None:
+            torch.cuda.synchronize(self._device)
+            self._graph = None
+        AnnEvaluator._live.discard(self)
 
     def eval(self, q):
         """N(q) into qs_out and (dN/dq)^T into jt_out for the batch q (B, n), float64 in and out."""
@@ -763,23 +782,24 @@ def pod_ann_run(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, projection="LSPG",
     Ar, br, _, G = _workspace(c, n)
     st = _IterState(c, n)
     U0 = c.u0.clone()
-    for nt in range(nsteps):
-        _mass_rhs(c, U0, G)
-        qp = (U0 @ Up).contiguous()                                         # (:1197)
-        st.begin_step()
-        ann.eval(qp)                                                        # dN at the first guess (:1219)
-        while True:
-            rom_reduce(c, tangent.gemm(), U0, G, proj, True, st.active, Ar, br, None, colmajor=True)   # (:1224)
-            left = st.solve_update(3, Ar, br, None, qp, tol, max_it)        # q_p += dq           (:1237-1244)
-            ann.eval(qp)                            # q_s = N(q_p) for the decode (:1241) and dN for the next pass
-            U0 = (qp @ UpT + qs @ UsT).contiguous()                         # (:1242)
-            if left == 0:
-                break
-        iters[:, nt] = st.k
-        hist[:, nt + 1] = U0
-    flags |= st.flags
-    torch.cuda.current_stream(c.device).synchronize()
-    ann.release()
+    try:
+        for nt in range(nsteps):
+            _mass_rhs(c, U0, G)
+            qp = (U0 @ Up).contiguous()                                         # (:1197)
+            st.begin_step()
+            ann.eval(qp)                                                        # dN at the first guess (:1219)
+            while True:
+                rom_reduce(c, tangent.gemm(), U0, G, proj, True, st.active, Ar, br, None, colmajor=True)   # (:1224)
+                left = st.solve_update(3, Ar, br, None, qp, tol, max_it)        # q_p += dq           (:1237-1244)
+                ann.eval(qp)                            # q_s = N(q_p) for the decode (:1241) and dN for the next pass
+                U0 = (qp @ UpT + qs @ UsT).contiguous()                         # (:1242)
+                if left == 0:
+                    break
+            iters[:, nt] = st.k
+            hist[:, nt + 1] = U0
+        flags |= st.flags
+    finally:
+        ann.release()               # also on an exception (SingularReducedSystem): never leave the graph to the collector
     return FomResult(hist, iters, flags)
 
 

@@ -63,7 +63,17 @@ def parse_args(argv=None):
     ap.add_argument("--dt", type=float, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU-baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-configs", choices=("auto", "full", "small", "none"), default="auto",
+                    help="1-GPU fom run: append short runs of BASELINE configs[2..4] as other_configs.  auto = full for the "
+                         "driver's default command line, none once a workload flag is given; small = 96 samples x 12 steps "
+                         "(the contract test)")
+    ap.add_argument("--other-steps", type=int, default=2, help="timed passes of each other_configs entry")
     args = ap.parse_args(argv)
+    # the driver's own line (no workload flag given): configs[1] as the headline + one short run of every other config
+    args.default_workload = (args.config == "fom" and args.batch is None and args.n is None and args.dt is None
+                             and args.time_steps == 500)
+    if args.other_configs == "auto":
+        args.other_configs = "full" if args.default_workload else "none"
     rom = args.config != "fom"
     if args.steps is None:
         args.steps = 3 if rom else 10
@@ -356,12 +366,20 @@ class AnnWorkload(RomWorkload):
         self.flops_per_step = 2 * 132000 * (1 + n) + 2 * N * (n + nb) * (1 + n) + 2 * N * n * n + 11 * N * n
         self.u0 = torch.ones((self.args.batch, N), dtype=torch.float64, device=self.dev)
         self.mu1d, self.mu2d = torch.as_tensor(self.mu1, device=self.dev), torch.as_tensor(self.mu2, device=self.dev)
+        # everything that does not depend on the batch is built once, outside the timed passes: the closure as
+        # bg_ann_rom_run wants it (recognised-MLP probe, padded weight uploads) and the device-resident bases
+        from burgers_hip import rom
+        self.model = self.model.to(device=self.dev, dtype=torch.float32).eval()
+        self.Up = torch.as_tensor(self.g["U_p"], device=self.dev)
+        self.Us = torch.as_tensor(self.g["U_s"], device=self.dev)
+        self.plan = rom._ann_fused_plan(self.model, n, nb, N, torch.float32, self.dev)
+        assert self.plan is not None, "the committed closure must take the device-side loop (bg_ann_rom_run)"
 
     def one_pass(self):
         from burgers_hip import rom
         a = self.args
-        return rom.pod_ann_run(self.X, self.u0, self.mu1d, self.mu2d, a.dt, a.time_steps, self.g["U_p"], self.g["U_s"],
-                               self.model, device=self.dev)
+        return rom.pod_ann_run_fused(self.X, self.u0, self.mu1d, self.mu2d, a.dt, a.time_steps, self.Up, self.Us,
+                                     self.model, rom.PROJ["lspg"], tol=1e-6, max_it=50, device=self.dev, plan=self.plan)
 
     def roofline(self, units, kernel_s):
         r = super().roofline(units, kernel_s)
@@ -595,6 +613,60 @@ def allgather_svd_ms(w, res, dist_mod, backend):
             "backend": backend}
 
 
+def timed_passes(w, warmup, steps, barrier):
+    """``warmup`` untimed passes, then exactly ``steps`` passes bracketed by barrier + synchronize on both sides.
+    Returns (last result, wall seconds of the timed region, per-pass ms by HIP events on the launch stream)."""
+    import torch
+    res = None
+    for _ in range(warmup):
+        res = w.one_pass()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record()                      # our kernels are launched on torch's current stream (lib.stream_ptr)
+        res = w.one_pass()
+        e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return res, elapsed, [e0.elapsed_time(e1) for e0, e1 in evs]
+
+
+def other_config_entries(args, dev, barrier):
+    """The default 1-GPU run also measures BASELINE configs[2..4]: each --config workload at its own
+    full size for a few passes, same timing protocol as the headline, parity of a sample subset against the CPU
+    restatement outside the timed region.  One compact entry each; the full line of a config is `--config NAME`."""
+    import gc
+    import numpy as np
+    import torch
+    out = []
+    for cfg in CONFIGS[1:]:
+        t_all = time.perf_counter()
+        try:
+            small = ["--batch", "96", "--time-steps", "12"] if args.other_configs == "small" else []
+            a2 = parse_args(["--config", cfg, "--warmup", "1", "--steps", str(args.other_steps)] + small)
+            w = WORKLOADS[cfg](a2, 0, 1, dev)
+            res, elapsed, pass_ms = timed_passes(w, a2.warmup, a2.steps, barrier)
+            units = w.units(res)
+            par, _ = cpu_leg(w, res, timed=False)
+            roof = w.roofline(units, float(np.mean(pass_ms)) * 1e-3)
+            entry = {"config": {"workload": w.describe()[1], "name": cfg, "global_batch": a2.batch, "units_per_pass": units},
+                     "value": units * a2.steps / elapsed, "unit": w.unit, "ms_per_step": elapsed / a2.steps * 1e3,
+                     "steps": a2.steps, "warmup": a2.warmup, "dtype": w.dtype,
+                     "roofline": {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")}}
+            entry.update(par)
+            entry.update(w.status(res))
+        except Exception as e:                               # the headline line must survive a failing side run
+            entry = {"config": {"name": cfg}, "error": f"{type(e).__name__}: {e}"}
+        w = res = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        entry["wall_s_incl_setup_and_parity"] = time.perf_counter() - t_all
+        out.append(entry)
+        print(f"bench.py: other_configs[{cfg}] done in {entry['wall_s_incl_setup_and_parity']:.1f} s", file=sys.stderr)
+    return out
+
+
 def run_rank(args):
     # Exactly ONE line may reach stdout, and libraries below us write there too (gloo announces its connections on fd 1):
     # everything printed while the rank runs goes to stderr, the JSON line alone to the real stdout.
@@ -642,19 +714,7 @@ def _run_rank(args, real_stdout):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    res = None
-    for _ in range(args.warmup):
-        res = w.one_pass()
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()                      # our kernels are launched on torch's current stream (lib.stream_ptr)
-        res = w.one_pass()
-        e1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    pass_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    res, elapsed, pass_ms = timed_passes(w, args.warmup, args.steps, barrier)
 
     units = w.units(res)                                     # units in one pass, this rank
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -686,6 +746,10 @@ def _run_rank(args, real_stdout):
         if gather is not None:
             line["allgather_svd"] = gather
             line["allgather_svd_ms"] = gather["allgather_svd_ms"]
+        if args.gpus == 1 and args.config == "fom" and args.other_configs != "none":
+            w = res = None
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_config_entries(args, dev, barrier)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()

@@ -118,8 +118,12 @@ def test_ann_fused_shapes_and_activations(hip, N, n, nbar, hidden, act, bias):
         assert hasattr(f, "info") and not hasattr(b, "info")
         fi, bi = f.iters.cpu().numpy(), b.iters.cpu().numpy()
         assert np.abs(fi - bi).max() <= 1
+        # the two paths must agree on WHICH samples hit the cap / went non-finite (one sample of slack, as for the
+        # iteration counts: the float32 closure can put a sample on either side of the threshold), and most samples
+        # must be clean so that the trajectories below are really compared
+        assert int((f.flags != b.flags).sum().item()) <= 1, (proj, f.flags.tolist(), b.flags.tolist())
         ok = ((f.flags == 0) & (b.flags == 0)).cpu().numpy()
-        assert ok.any()
+        assert ok.mean() >= 0.8, (proj, f.flags.tolist())
         fh, bh = f.hist.cpu().numpy(), b.hist.cpu().numpy()
         for s in np.flatnonzero(ok):
             assert rel_l2(fh[s], bh[s]) < TOL32, (proj, s)

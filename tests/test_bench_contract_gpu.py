@@ -55,6 +55,20 @@ def test_bench_rom_configs(hip, config, batch):
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
 
 
+def test_bench_default_line_carries_the_other_configs(hip):
+    """The driver's default command line also measures configs[2..4] (other_configs): here at the small size."""
+    d = _run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "64",
+              "--time-steps", "20", "--no-cpu-baseline", "--other-configs", "small", "--other-steps", "1"])
+    oc = d["other_configs"]
+    assert [e["config"]["name"] for e in oc] == ["pod_galerkin", "pod_lspg", "quadratic", "ann", "decoder_bf16"]
+    for e in oc:
+        assert "error" not in e, e
+        assert e["value"] > 0 and e["ms_per_step"] > 0 and e["steps"] == 1 and 0.0 < e["roofline"]["frac"] <= 1.0
+        assert e["rel_l2_vs_cpu_ref"] < e["parity_tolerance"] and e["nonfinite_samples"] == 0
+        if e["config"]["name"] in ("pod_galerkin", "pod_lspg", "quadratic"):
+            assert e["iters_match_cpu_ref"] is True
+
+
 def test_bench_decoder_bf16(hip):
     d = _run([sys.executable, os.path.join(REPO, "bench.py"), "--config", "decoder_bf16", "--steps", "1", "--warmup", "1",
               "--batch", "300", "--time-steps", "100"])
