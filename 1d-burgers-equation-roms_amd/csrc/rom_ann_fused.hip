@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 __syncthreads();
                 lap(0);
                 if constexpr (!skip(1))
-                    mfma_pass<S, NB, GAL, 0, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
+                    mfma_pass<S, NB, GAL, 0, NB, true, RW>(frag, HaloTable<NB>{s_halo, tid}, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
                 __syncthreads();
                 lap(1);
                 // ---- reduced solve -------------------------------------------------------------------------------

@@ -46,8 +46,14 @@ struct RomRunArgs {
     int N, B, r, nsteps, max_it, supg, nonuniform, force_pivoted;
 };
 
+// Two workgroups per CU (round 3): the fp64 MFMAs of a wave do not overlap with its own vector-ALU work
+// (tools/mfma_valu_bench.hip), but the matrix pipe and the VALU of a SIMD serve different waves at the same time, so a
+// second resident sample fills the phases in which the first one solves, lifts or waits at a barrier.  What that takes
+// is LDS <= 80 KB per workgroup (was 135 KB): the per-thread halo table (40 KB) became register traffic between
+// neighbouring lanes (HaloLanes), and the four per-wave partial systems (56 KB) two that wave pairs share (NRED = 2).
+// The repair kernel (PIV) keeps one workgroup per CU: its one-wave pivoted solve holds a 41-double row per lane.
 template <int S, int NB, int PROJ, bool PIV>
-__global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
+__global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs a)
 {
     constexpr int NPAD = 64 * S;
     constexpr int RW = 4 * NB;                   // padded reduced dimension
@@ -57,9 +63,18 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
     __shared__ double s_h[NPAD];                 // hfs: h_e (f(gp1) + f(gp2)) per element
     __shared__ double s_fdt[NPAD];               // dt F
     __shared__ double s_coef[NPAD][4];
-    __shared__ double s_red[4][RW][RW + 4];      // per-wave  Ar | [br, W^T u (Galerkin), 0, 0]
+#ifndef BG_ACC_BUDGET
+#define BG_ACC_BUDGET (((256 - 2 * S * NB - 56) / 2) < 24 ? ((256 - 2 * S * NB - 56) / 2) : 24)
+#endif
+    // accumulators a pass may keep live: what 256 registers leave beside the 2 S NB fragment registers and ~56 others (measured at r = 40, N = 512: 16 ... 24 accumulators run alike, 30 spill into the MFMA loop and lose 25 %)
+    constexpr int kAccBudget = PIV ? 64 : (BG_ACC_BUDGET);
+#ifndef BG_NRED
+#define BG_NRED 2
+#endif
+    constexpr int NRED = BG_NRED;
+    __shared__ double s_red[NRED][RW][RW + 4];   // per wave pair {w, w + 2}:  Ar | [br, W^T u (Galerkin), 0, 0]
     __shared__ double s_wtu[4][RW];              // per-wave  W^T u (LSPG)
-    __shared__ double s_halo[2][NB][256];        // Phi rows just below / above every thread's S rows, per column block
+    __shared__ double s_edge[2][NB][4][4];       // Phi rows just below / above each WAVE's 16 S rows, per column block and t
     __shared__ double s_m[2][4][64];             // multipliers of the current / next panel
     __shared__ double s_diag[RW], s_y[RW];       // what the elimination leaves: diagonal and right-hand side
     __shared__ double s_q[RW];
@@ -83,10 +98,16 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
             const int i = rowbase + s;
             frag[c][s] = (i < N && col < r) ? a.Phi[(size_t)i * r + col] : 0.0;
         }
-        const int il = rowbase - 1, ih = rowbase + S;
-        s_halo[0][c][tid] = (il >= 0 && il < N && col < r) ? a.Phi[(size_t)il * r + col] : 0.0;
-        s_halo[1][c][tid] = (ih < N && col < r) ? a.Phi[(size_t)ih * r + col] : 0.0;
+        if ((lane >> 2) == 0) {                  // the row below this wave's first row (inside a wave: HaloLanes)
+            const int il = rowbase - 1;
+            s_edge[0][c][w][t] = (il >= 0 && il < N && col < r) ? a.Phi[(size_t)il * r + col] : 0.0;
+        }
+        if ((lane >> 2) == 15) {
+            const int ih = rowbase + S;
+            s_edge[1][c][w][t] = (ih < N && col < r) ? a.Phi[(size_t)ih * r + col] : 0.0;
+        }
     }
+    const HaloLanes<NB> halo{s_edge, w, t, lane};
     if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;      // halos [0], [1], [NPAD+2], [NPAD+3]
 
     for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
@@ -174,35 +195,28 @@ __global__ __launch_bounds__(256, 1) void rom_fused_kernel(RomRunArgs a)
                 __syncthreads();
                 lap(0);
                 // ---- projection on the matrix cores -----------------------------------------------------------------
-                // Galerkin: two passes over the rows with half of the (NB + 1) NB accumulators live in each (one pass spills at
-                // r = 40); LSPG: its NB (NB + 1) / 2 + 2 NB accumulators fit one pass, which forms the operands once.
-                constexpr int CM = GAL ? NB / 2 : 0;
-                if constexpr (skip(1)) {
-                } else if constexpr (CM == 0) {
-                    mfma_pass<S, NB, GAL, 0, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
-                } else {
-                    mfma_pass<S, NB, GAL, 0, CM, false, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
-                    mfma_pass<S, NB, GAL, CM, NB, true, RW>(frag, s_halo, s_coef, s_u, rowbase, t, w, lane, tid, s_red, s_wtu);
-                }
+                // as many passes over the rows as the accumulator budget of this instantiation demands (mfma_passes)
+                if constexpr (!skip(1))
+                    mfma_passes<S, NB, GAL, RW, NRED, kAccBudget>(frag, halo, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
                 __syncthreads();
                 lap(1);
                 // ---- reduced solve: load own columns (sum of the four waves' partials), eliminate ----------------
                 auto entry = [&](int i, int j) -> double {               // (Ar | br | wtu)[i][j], j <= RW + 1
                     int rr = i, cc = j;
                     if (!GAL && j < RW && (i >> 2) > (j >> 2)) { rr = j; cc = i; }   // LSPG: mirror the lower blocks
-                    return (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
+                    return red_sum<NRED, RW>(s_red, rr, cc);
                 };
                 double xout = 0.0;
                 if constexpr (PIV) {
                     if (tid == 0) s_info = 0;
                     __syncthreads();
-                    if (w == 0) pivoted_solve<NB, GAL>(s_red, s_x, &s_info, lane, r);
+                    if (w == 0) pivoted_solve<NB, GAL, NRED>(s_red, s_x, &s_info, lane, r);
                     __syncthreads();
                     xout = (lane < RW) ? s_x[lane] : 0.0;
                     if (s_info != 0 && info_out == 0) info_out = s_info;
                 } else {
                     bool tripped;
-                    xout = coop_gj_solve<NB, GAL, !skip(2)>(s_red, s_m, s_diag, s_y, s_bad, w, lane, r, tripped);
+                    xout = coop_gj_solve<NB, GAL, !skip(2), NRED>(s_red, s_m, s_diag, s_y, s_bad, w, lane, r, tripped);
                     if (!kTiming && tripped) aborted = true;
                 }
                 lap(2);
@@ -306,7 +320,8 @@ int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double* x,
     a.supg = options & BG_OPT_SUPG; a.nonuniform = (options & BG_OPT_NONUNIFORM) ? 1 : 0;
     a.force_pivoted = (options & BG_OPT_FORCE_PIVOTED) ? 1 : 0;
     const int cus = device_cu_count();
-    const int grid = B < cus ? B : cus;
+    const int grid = B < 2 * cus ? B : 2 * cus;              // two resident workgroups per CU
+    const int grid_repair = B < cus ? B : cus;
     hipStream_t st = (hipStream_t)stream;
     const int nb = r <= 8 ? 2 : (r <= 24 ? 6 : 10);
     const int s4 = N <= 256 ? 4 : 8;
@@ -325,7 +340,7 @@ int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double* x,
         const int rc = check_launch();
         if (rc != BG_OK) return rc;
     }
-    if (kAblate < 0) launch_repair(projection, grid, st, a);     // every workgroup leaves at once unless a sample is flagged
+    if (kAblate < 0) launch_repair(projection, grid_repair, st, a);     // every workgroup leaves at once unless a sample is flagged
     return check_launch();
 }
 

@@ -20,20 +20,60 @@ constexpr bool kTiming = kAblate >= 0;
 constexpr bool skip(int bit) { return kTiming && (kAblate & bit) != 0; }
 
 
+// LDS  *p += v  without a return value: ds_add_f64.  Callers give every address exactly one adder per barrier interval,
+// so the sum does not depend on the order in which waves arrive.
+__device__ __forceinline__ void lds_add_f64(double* p, double v)
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ---- one MFMA pass over this wave's rows: pairs (ca, cb) with ca in [CA0, CA1) (LSPG) / cb in [CA0, CA1) (Galerkin) ----
-// Same operand layout, accumulation order and block-partial summation as rom_reduce4_kernel (rom.hip), so the
-// reduced system has the bits of the batched path.  frag[c][s] = Phi[rowbase + s][4 c + t]; the two halo rows
-// Phi[rowbase - 1], Phi[rowbase + S] of every column block sit in LDS (s_halo[0 / 1][c][tid], one private slot per
-// thread: conflict-free 8-byte reads) and are fetched when the first / last row step needs them -- 40 VGPRs fewer
-// live across the whole kernel.  LAST: this pass also carries the Phi^T u accumulators of the LSPG form / the [R, u]
-// column of the Galerkin form.  The Galerkin passes split the B side (cb): a pass forms only the (A Phi) operands of its own
-// column blocks, so two passes form every operand once (a split of the A side formed all of them twice: 240 instructions).
-template <int S, int NB, bool GAL, int CA0, int CA1, bool LAST, int RW>
-__device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const double (*__restrict__ s_halo)[NB][256],
+// Same operand layout and accumulation order as rom_reduce4_kernel (rom.hip).  frag[c][s] = Phi[rowbase + s][4 c + t]; the
+// two halo rows Phi[rowbase - 1], Phi[rowbase + S] of every column block come from `halo(side, c)` when the first / last
+// row step needs them (they are not kept in registers: 40 VGPRs fewer live across the whole kernel):
+//   HaloTable   one private LDS slot per thread (s_halo[side][c][tid], conflict-free 8-byte reads): rom_ann_fused, whose
+//               tangent changes every iteration and is written to LDS anyway;
+//   HaloLanes   the neighbouring owner's fragment registers through ds_bpermute (lane -+ 4 holds the same column of the
+//               row below / above), and a 2.5 KB LDS table for the four lanes per side whose neighbour is in another
+//               wave: rom_fused, where the basis is constant -- the 40 KB table of the first form is what kept that kernel
+//               at one workgroup per CU.
+// LAST: this pass also carries the Phi^T u accumulators of the LSPG form / the [R, u] column of the Galerkin form.  The
+// Galerkin passes split the B side (cb): a pass forms only the (A Phi) operands of its own column blocks, so two passes
+// form every operand once (a split of the A side formed all of them twice: 240 instructions).
+// NRED: how the four waves' partial systems meet.  4: one LDS buffer per wave, summed by the reader as
+// (w0 + w1) + (w2 + w3) (the batched path's order).  2: waves 0, 1 store, a workgroup barrier, waves 2, 3 add theirs on
+// top (every address receives exactly one add: the result does not depend on timing); the reader sums
+// (w0 + w2) + (w1 + w3).  Half the LDS (28 KB instead of 56 KB at r = 40) for one more barrier per pass.
+template <int NB>
+struct HaloTable {
+    const double (*tab)[NB][256];
+    int tid;
+    template <int S>
+    __device__ __forceinline__ double operator()(int side, int c, const double (&)[NB][S]) const { return tab[side][c][tid]; }
+};
+
+template <int NB>
+struct HaloLanes {
+    const double (*edge)[NB][4][4];      // [side][c][wave][t]: the rows just outside each wave's 16 S rows
+    int w, t, lane;
+    template <int S>
+    __device__ __forceinline__ double operator()(int side, int c, const double (&frag)[NB][S]) const
+    {
+        const double mine = side == 0 ? frag[c][S - 1] : frag[c][0];
+        const int src = side == 0 ? lane - 4 : lane + 4;
+        const double nb = from_lane_rot(mine, (src & 63) << 2);
+        const bool outside = side == 0 ? lane < 4 : lane >= 60;
+        return outside ? edge[side][c][w][t] : nb;
+    }
+};
+
+template <int S, int NB, bool GAL, int CA0, int CA1, bool LAST, int RW, int NRED = 4, class Halo>
+__device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const Halo& halo,
                                           const double (*__restrict__ s_coef)[4], const double* __restrict__ s_u,
-                                          int rowbase, int t, int w, int lane, int tid,
+                                          int rowbase, int t, int w, int lane,
                                           double (*__restrict__ s_red)[RW][RW + 4], double (*__restrict__ s_wtu)[RW])
 {
+    static_assert(NRED == 4 || NRED == 2, "four per-wave partial systems, or two shared by wave pairs");
     constexpr int NROW = GAL ? (CA1 - CA0) * NB : (CA1 - CA0) * (2 * NB - CA0 - CA1 + 1) / 2 + (CA1 - CA0);
     constexpr int NACC = NROW + (LAST ? NB : 0);
     double acc[NACC];
@@ -46,8 +86,8 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const dou
         const double ui = s_u[i + 2];
 #pragma unroll
         for (int c = (GAL ? CA0 : 0); c < (GAL ? CA1 : NB); ++c) {
-            const double below = (s == 0) ? s_halo[0][c][tid] : frag[c][s == 0 ? 0 : s - 1];
-            const double above = (s == S - 1) ? s_halo[1][c][tid] : frag[c][s == S - 1 ? s : s + 1];
+            const double below = (s == 0) ? halo(0, c, frag) : frag[c][s == 0 ? 0 : s - 1];
+            const double above = (s == S - 1) ? halo(1, c, frag) : frag[c][s == S - 1 ? s : s + 1];
             double y = lo * below;
             y = __builtin_fma(di, frag[c][s], y);
             y = __builtin_fma(up, above, y);
@@ -92,58 +132,92 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const dou
         }
         __builtin_amdgcn_sched_barrier(0);       // nothing moves across a step: bounded register pressure
     }
-    // sum the four block partials of every pair (lanes differing in bits 2..3), park them per wave in LDS
+    // sum the four block partials of every pair (lanes differing in bits 2..3), park them per wave (pair) in LDS
     const int oi = lane >> 4, oj = lane & 3;
     const bool writer = ((lane >> 2) & 3) == 3;
-    int p = 0;
     if constexpr (skip(32)) {                    // timing only: keep the MFMAs alive, drop the block sums and stores
         double v = 0.0;
 #pragma unroll
         for (int q = 0; q < NACC; ++q) v += acc[q];
-        if (writer) s_red[w][oi][oj] = v;
-        return;
-    }
-    if constexpr (GAL) {
-#pragma unroll
-        for (int ca = 0; ca < NB; ++ca) {
-#pragma unroll
-            for (int cb = CA0; cb < CA1; ++cb, ++p) {
-                double v = acc[p];
-                v += dpp_mov<0x114>(v);          // row_shr:4
-                v += dpp_mov<0x118>(v);          // row_shr:8 -> lanes with blk == 3 hold the sum
-                if (writer) s_red[w][4 * ca + oi][4 * cb + oj] = v;
-            }
-        }
-        if constexpr (LAST) {
-#pragma unroll
-            for (int ca = 0; ca < NB; ++ca, ++p) {
-                double v = acc[p];
-                v += dpp_mov<0x114>(v);
-                v += dpp_mov<0x118>(v);
-                if (writer) s_red[w][4 * ca + oi][4 * NB + oj] = v;
-            }
-        }
+        if (writer) s_red[NRED == 4 ? w : (w & 1)][oi][oj] = v;
+        if constexpr (NRED == 2) __syncthreads();
         return;
     }
 #pragma unroll
-    for (int ca = CA0; ca < CA1; ++ca) {
+    for (int q = 0; q < NACC; ++q) {
+        double v = acc[q];
+        v += dpp_mov<0x114>(v);                  // row_shr:4
+        v += dpp_mov<0x118>(v);                  // row_shr:8 -> lanes with blk == 3 hold the sum
+        acc[q] = v;
+    }
+    // visit every accumulator with its place in the reduced system: f(p, row block, column block)
+    auto for_each_acc = [&](auto&& f) {
+        int p = 0;
+        if constexpr (GAL) {
 #pragma unroll
-        for (int cb = ca; cb <= NB; ++cb, ++p) {
-            double v = acc[p];
-            v += dpp_mov<0x114>(v);          // row_shr:4
-            v += dpp_mov<0x118>(v);          // row_shr:8 -> lanes with blk == 3 hold the sum
-            if (writer) s_red[w][4 * ca + oi][4 * cb + oj] = v;
+            for (int ca = 0; ca < NB; ++ca) {
+#pragma unroll
+                for (int cb = CA0; cb < CA1; ++cb, ++p) f(p, ca, cb);
+            }
+            if constexpr (LAST) {
+#pragma unroll
+                for (int ca = 0; ca < NB; ++ca, ++p) f(p, ca, NB);
+            }
+        } else {
+#pragma unroll
+            for (int ca = CA0; ca < CA1; ++ca) {
+#pragma unroll
+                for (int cb = ca; cb <= NB; ++cb, ++p) f(p, ca, cb);
+            }
         }
+    };
+    if constexpr (NRED == 4) {
+        for_each_acc([&](int p, int ca, int cb) { if (writer) s_red[w][4 * ca + oi][4 * cb + oj] = acc[p]; });
+    } else {
+        double (*dst)[RW + 4] = s_red[w & 1];
+        if (w < 2) for_each_acc([&](int p, int ca, int cb) { if (writer) dst[4 * ca + oi][4 * cb + oj] = acc[p]; });
+        __syncthreads();
+        if (w >= 2) for_each_acc([&](int p, int ca, int cb) { if (writer) lds_add_f64(&dst[4 * ca + oi][4 * cb + oj], acc[p]); });
     }
     if constexpr (!GAL && LAST) {
+        constexpr int P0 = NROW;
 #pragma unroll
-        for (int ca = 0; ca < NB; ++ca, ++p) {
-            double v = acc[p];
-            v += dpp_mov<0x114>(v);
-            v += dpp_mov<0x118>(v);
-            if (writer && oj == 1) s_wtu[w][4 * ca + oi] = v;
-        }
+        for (int ca = 0; ca < NB; ++ca)
+            if (writer && oj == 1) s_wtu[w][4 * ca + oi] = acc[P0 + ca];
     }
+}
+
+// ---- the projection as a sequence of passes sized for a register budget -------------------------------------------
+// A pass keeps NACC accumulators live next to the basis fragments.  With two workgroups per CU a lane has 256 registers,
+// 2 S NB of them hold the fragments, so the (NB + 1) NB (Galerkin) / NB (NB + 1) / 2 + 2 NB (LSPG) accumulators are
+// produced in as many passes as a budget of BUDGET accumulators demands.  Galerkin passes split the column blocks cb of
+// the B side, LSPG passes the row blocks ca; the last pass carries the [R, u] / Phi^T u extras.
+template <int NB, bool GAL>
+constexpr int pass_acc_count(int c0, int c1)
+{
+    int n = 0;
+    for (int c = c0; c < c1; ++c) n += GAL ? NB : NB - c + 1;
+    return n + (c1 == NB ? NB : 0);
+}
+
+template <int NB, bool GAL, int BUDGET>
+constexpr int pass_end(int c0)
+{
+    int c1 = c0 + 1;
+    while (c1 < NB && pass_acc_count<NB, GAL>(c0, c1 + 1) <= BUDGET) ++c1;
+    return c1;
+}
+
+template <int S, int NB, bool GAL, int RW, int NRED, int BUDGET, int C0 = 0, class Halo>
+__device__ __forceinline__ void mfma_passes(const double (&frag)[NB][S], const Halo& halo,
+                                            const double (*__restrict__ s_coef)[4], const double* __restrict__ s_u,
+                                            int rowbase, int t, int w, int lane,
+                                            double (*__restrict__ s_red)[RW][RW + 4], double (*__restrict__ s_wtu)[RW])
+{
+    constexpr int C1 = pass_end<NB, GAL, BUDGET>(C0);
+    mfma_pass<S, NB, GAL, C0, C1, C1 == NB, RW, NRED>(frag, halo, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
+    if constexpr (C1 < NB)
+        mfma_passes<S, NB, GAL, RW, NRED, BUDGET, C1>(frag, halo, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
 }
 
 // ---- cooperative unpivoted elimination (see the file header) ----------------------------------------------------
@@ -189,7 +263,15 @@ __device__ __forceinline__ void lu_factor_panel(double (&c)[4], int p, int lane,
 // The partial-pivoting solve of the repair kernel (PIV): one wave reloads the summed system from the per-wave partials and
 // runs the routine of bg_lu_solve.  It lives in a kernel of its own: as a cold branch (even out of line) inside the fast
 // kernel it cost 4.7 us per iteration through the register allocation around the call site.
-template <int NB, bool GAL>
+// sum of the per-wave (NRED = 4) / per-wave-pair (NRED = 2, see mfma_pass) partial systems
+template <int NRED, int RW>
+__device__ __forceinline__ double red_sum(const double (*__restrict__ s_red)[RW][RW + 4], int rr, int cc)
+{
+    if constexpr (NRED == 4) return (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
+    else return s_red[0][rr][cc] + s_red[1][rr][cc];
+}
+
+template <int NB, bool GAL, int NRED = 4>
 __device__ __forceinline__ void pivoted_solve(const double (*__restrict__ s_red)[4 * NB][4 * NB + 4],
                                               double* __restrict__ s_x, int* __restrict__ s_info, int lane, int r)
 {
@@ -197,7 +279,7 @@ __device__ __forceinline__ void pivoted_solve(const double (*__restrict__ s_red)
     auto entry = [&](int i, int j) -> double {
         int rr = i, cc = j;
         if (!GAL && j < RW && (i >> 2) > (j >> 2)) { rr = j; cc = i; }
-        return (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
+        return red_sum<NRED, RW>(s_red, rr, cc);
     };
     double row[RW + 1];
 #pragma unroll
@@ -213,7 +295,7 @@ __device__ __forceinline__ void pivoted_solve(const double (*__restrict__ s_red)
 // In: the four per-wave partial systems s_red (+ mirror for LSPG); r = live unknowns (the rest is identity padding).
 // Out: x_k in lane k of EVERY wave (identical values); tripped = a multiplier above 1 or a zero pivot was seen (then x is
 // not to be used).  Contains workgroup barriers: all 256 threads call it.  ELIM = false compiles the panels out (timing).
-template <int NB, bool GAL, bool ELIM = true>
+template <int NB, bool GAL, bool ELIM = true, int NRED = 4>
 __device__ __forceinline__ double coop_gj_solve(const double (*__restrict__ s_red)[4 * NB][4 * NB + 4],
                                                 double (*__restrict__ s_m)[4][64], double* __restrict__ s_diag,
                                                 double* __restrict__ s_y, int* __restrict__ s_bad, int w, int lane, int r,
@@ -224,7 +306,7 @@ __device__ __forceinline__ double coop_gj_solve(const double (*__restrict__ s_re
     auto entry = [&](int i, int j) -> double {               // (Ar | br)[i][j], j <= RW
         int rr = i, cc = j;
         if (!GAL && j < RW && (i >> 2) > (j >> 2)) { rr = j; cc = i; }   // LSPG: mirror the lower blocks
-        return (s_red[0][rr][cc] + s_red[1][rr][cc]) + (s_red[2][rr][cc] + s_red[3][rr][cc]);
+        return red_sum<NRED, RW>(s_red, rr, cc);
     };
     LuRegs<NB> lu;
 #pragma unroll
