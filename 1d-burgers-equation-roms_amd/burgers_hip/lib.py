@@ -31,6 +31,7 @@ BG_OPT_SUPG, BG_OPT_NONUNIFORM, BG_OPT_W_COLMAJOR, BG_OPT_MFMA_16X16, BG_OPT_FOR
 BG_ACT_NONE, BG_ACT_ELU, BG_ACT_RELU, BG_ACT_TANH = 0, 1, 2, 3
 BG_COUNTER_SLOTS, BG_COUNTER_STRIDE = 16, 32
 BG_RBF_GAUSSIAN, BG_RBF_IMQ = 0, 1
+BG_INFO_NEEDS_PIVOTING = -1
 
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -79,6 +80,13 @@ _SIGNATURES = {
     "bg_rom_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                   c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
+    "bg_quad_rom_max_n": (ctypes.c_int, []),
+    "bg_quad_rom_h3f_elems": (ctypes.c_longlong, [ctypes.c_int]),
+    "bg_quad_rom_phif_elems": (ctypes.c_longlong, [ctypes.c_int]),
+    "bg_quad_rom_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                       c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p,
+                                       ctypes.c_void_p]),
     "bg_rom_lift": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                    c_int_p, c_double_p, ctypes.c_void_p]),
     "bg_quad_features": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_double_p, ctypes.c_void_p]),

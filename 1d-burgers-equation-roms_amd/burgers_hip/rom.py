@@ -412,13 +412,88 @@ def sym_index_tables(n, device):
             torch.as_tensor(idx, device=device), torch.as_tensor(fac, device=device))
 
 
+def quad_tangent_tensor(Phid, Hd):
+    """H3[i][a][c] = H[i][pair(a, c)] (1 + delta_ac), (N, n, n): tangent = Phi + H3 . q (:1120-1123 with get_dQ_dq
+    :292-312 folded in)."""
+    n = Phid.shape[1]
+    _, _, idx, fac = sym_index_tables(n, Phid.device)
+    return (Hd[:, idx] * fac).contiguous()
+
+
+class QuadFusedPlan:
+    """The operand copies bg_quad_rom_run reads, built once per (Phi, H) on the device (include/burgers_hip.h):
+    Phi^T zero padded, the accumulator seeds of the tangent tiles, and H3 in the A-operand order of the matrix
+    instruction.  None-like (``ok`` False) when the basis is beyond the kernel (N > 512 or n > 40)."""
+
+    def __init__(self, Phi, H, device):
+        L = _lib.load()
+        self.Phi, self.H = _as_dev(Phi, device), _as_dev(np.ascontiguousarray(H) if isinstance(H, np.ndarray) else H, device)
+        N, n = self.Phi.shape
+        self.N, self.n = N, n
+        if self.H.shape != (N, n * (n + 1) // 2):
+            raise ValueError("Phi must be (N, n) and H (N, n(n+1)/2)")
+        self.ok = N <= 512 and n <= L.bg_quad_rom_max_n()
+        if not self.ok:
+            return
+        f64 = dict(dtype=torch.float64, device=device)
+        NG, NPAD = (N + 3) // 4, (N + 63) // 64 * 64
+        self.PhiT = torch.zeros((40, NPAD), **f64)
+        self.PhiT[:n, :N] = self.Phi.t()
+        Pp = torch.zeros((4 * NG, 40), **f64)
+        Pp[:N, :n] = self.Phi
+        # (rg, blk, i, c) -> [rg][c][4 i + blk]
+        self.Phif = Pp.reshape(NG, 4, 4, 10).permute(0, 3, 2, 1).contiguous()
+        H3p = torch.zeros((4 * NG, 40, 40), **f64)
+        H3p[:N, :n, :n] = quad_tangent_tensor(self.Phi, self.H)
+        # row 4 rg + blk, column 10 i + c, k index 8 kc2 + 4 e + k:  (rg, blk, i, c, kc2, e, k) -> [rg][c][kc2][k][blk][i][e]
+        self.H3f = H3p.reshape(NG, 4, 4, 10, 5, 2, 4).permute(0, 3, 4, 6, 1, 2, 5).contiguous()
+        assert self.H3f.numel() == L.bg_quad_rom_h3f_elems(N) and self.Phif.numel() == L.bg_quad_rom_phif_elems(N)
+
+
+def quadratic_run_fused(X, u0, mu1, mu2, dt, nsteps, plan, proj, E=0.0, newton_tol=1e-6, newton_itmax=25, device=None):
+    """``pod_quadratic_manifold`` for a batch with the whole time loop on the device (bg_quad_rom_run): four samples
+    per workgroup, no host in the loop; the reduced solve pivots like np.linalg.solve."""
+    L = _lib.load()
+    device = _lib.require_device(device)
+    opts = _lib.mesh_options(check_mesh(X), supg=False)
+    Xd = _as_dev(X, device)
+    N = Xd.numel()
+    if N != plan.N:
+        raise ValueError("Phi must be (N, n) and H (N, n(n+1)/2)")
+    u0d, mu1d, mu2d = _batch_inputs(u0, mu1, mu2, N, device)
+    B = mu1d.numel()
+    hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
+    iters = torch.zeros((B, nsteps), dtype=torch.int32, device=device)
+    flags = torch.zeros((B,), dtype=torch.int32, device=device)
+    info = torch.zeros((B,), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        rc = L.bg_quad_rom_run(N, B, plan.n, int(nsteps), proj, _lib.ptr(Xd), _lib.ptr(plan.PhiT), _lib.ptr(plan.Phif),
+                               _lib.ptr(plan.H3f), _lib.ptr(u0d), _lib.ptr(mu1d), _lib.ptr(mu2d), float(dt), float(E),
+                               float(newton_tol), int(newton_itmax), int(opts), _lib.ptr(hist), _lib.ptr(iters),
+                               _lib.ptr(flags), _lib.ptr(info), _lib.stream_ptr(device))
+    _lib.check(rc, "bg_quad_rom_run")
+    res = FomResult(hist, iters, flags)
+    res.info = info              # checked lazily by the caller (a readback would synchronise)
+    res._keep = (plan, Xd, u0d, mu1d, mu2d)
+    return res
+
+
 def quadratic_run(X, u0, mu1, mu2, dt, nsteps, Phi, H, projection="LSPG", E=0.0, newton_tol=1e-6,
-                  newton_itmax=25, device=None):
-    """Batched ``pod_quadratic_manifold`` (no SUPG term in this variant, :1142)."""
+                  newton_itmax=25, device=None, fused=True, plan=None):
+    """Batched ``pod_quadratic_manifold`` (no SUPG term in this variant, :1142).  ``fused`` (default): the device-side
+    time loop bg_quad_rom_run where it applies (N <= 512, n <= 40); otherwise, or with ``fused=False``, the batched
+    iteration (bg_quad_tangent -> bg_rom_reduce_frag -> bg_lu_solve_update -> decode GEMM) driven from the host.
+    ``plan``: a QuadFusedPlan of (Phi, H) to reuse across calls."""
     p = projection.lower()
     if p not in PROJ:
         raise ValueError("projection must be 'Galerkin' or 'LSPG'")
     proj = PROJ[p]
+    if fused:
+        dev = _lib.require_device(device)
+        if plan is None:
+            plan = QuadFusedPlan(Phi, H, dev)
+        if plan.ok:
+            return check_singular(quadratic_run_fused(X, u0, mu1, mu2, dt, nsteps, plan, proj, E, newton_tol, newton_itmax, dev))
     c = _setup(X, u0, mu1, mu2, dt, E, device)
     Phid, Hd = _as_dev(Phi, c.device), _as_dev(np.ascontiguousarray(H) if isinstance(H, np.ndarray) else H, c.device)
     n = Phid.shape[1]

@@ -325,7 +325,8 @@ class PodWorkload(RomWorkload):
 
 class QuadWorkload(RomWorkload):
     kind = "quadratic"
-    kernel_name = "quad_tangent_kernel + rom_reduce4_kernel + lu_solve_kernel (per batched iteration)"
+    kernel_name = ("quad_fused_kernel (bg_quad_rom_run: one launch per pass, the whole time loop of four samples per "
+                   "workgroup; tangent, decode, projection and solve fused)")
 
     def __init__(self, *a):
         super().__init__(*a)
@@ -338,12 +339,14 @@ class QuadWorkload(RomWorkload):
         self.flops_per_step = 2 * N * (r + k) + 4 * N * k + 2 * N * r * r + 11 * N * r + (2 * r ** 3) / 3
         self.u0 = torch.ones((self.args.batch, N), dtype=torch.float64, device=self.dev)
         self.mu1d, self.mu2d = torch.as_tensor(self.mu1, device=self.dev), torch.as_tensor(self.mu2, device=self.dev)
+        from burgers_hip import rom
+        self.plan = rom.QuadFusedPlan(self.Phi, self.H, self.dev)      # operand copies of (Phi, H): once per basis
 
     def one_pass(self):
         from burgers_hip import rom
         a = self.args
         return rom.quadratic_run(self.X, self.u0, self.mu1d, self.mu2d, a.dt, a.time_steps, self.Phi, self.H,
-                                 projection="LSPG", device=self.dev)
+                                 projection="LSPG", device=self.dev, plan=self.plan)
 
     def describe(self):
         a = self.args

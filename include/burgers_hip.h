@@ -280,6 +280,32 @@ int bg_rom_reduce_frag(int N, int B, int r, int projection, const double *x, con
 int bg_mlp_act_jvp(int B, int n1, int h, float *z, const float *bias, int act, float alpha, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * bg_quad_rom_run -- batched replacement of FEMBurgers.pod_quadratic_manifold, the WHOLE time loop on the device
+ *   reference: FEM/fem_burgers.py:1081-1175 (decoder :1116-1118, tangent :1120-1123 with get_dQ_dq :292-312 folded
+ *   in, Newton loop :1126-1173); called by Quadratic_manifold/quadratic_prom_simulation.py:49-55.
+ *   One 256-thread workgroup owns FOUR samples for all time steps and iterations: tangent T = Phi + H3 q of the four
+ *   samples on v_mfma_f64_4x4x4_4b (H3 streamed once per four sample-iterations), decode u = 1/2 (Phi q + T q) from
+ *   the same rows, assembly, projection and the n x n solve per wave (csrc/quad_fused.hip).  No SUPG term (:1142).
+ *   N <= 512, n <= bg_quad_rom_max_n() (40).  Operand copies, built once per basis by the caller (zero padded):
+ *     PhiT [40][NPAD]               Phi^T, NPAD = N rounded up to 64
+ *     Phif [NG][10][16]             Phi[4 rg + blk][10 i + c] at [rg][c][4 i + blk], NG = ceil(N / 4)
+ *     H3f  [NG][10][5][64][2]       H3[4 rg + blk][10 i + c][8 kc2 + 4 e + k] at [rg][c][kc2][16 k + 4 blk + i][e],
+ *                                   H3[i][a][c] = H[i][pair(a, c)] (1 + delta_ac)   (the A operand of the matrix instruction)
+ *     sizes: bg_quad_rom_phif_elems(N), bg_quad_rom_h3f_elems(N) doubles.
+ *   Outputs as bg_rom_run: hist [B][nsteps+1][N], iters [B][nsteps] (Newton iterations per step), flags [B]
+ *   (BG_FLAG_HIT_CAP = "Newton did not converge" :1171, BG_FLAG_NONFINITE), info [B]: 0, or k + 1 when the reduced
+ *   system met an exactly zero pivot at elimination step k (np.linalg.solve :1161 raises LinAlgError: so does the facade).
+ *   options: BG_OPT_NONUNIFORM.
+ * --------------------------------------------------------------------------------- */
+int bg_quad_rom_max_n(void);
+long long bg_quad_rom_h3f_elems(int N);
+long long bg_quad_rom_phif_elems(int N);
+int bg_quad_rom_run(int N, int B, int n, int nsteps, int projection, const double *x, const double *PhiT,
+                    const double *Phif, const double *H3f, const double *u0, const double *mu1, const double *mu2,
+                    double dt, double E, double tol, int max_it, int options, double *hist, int32_t *iters,
+                    int32_t *flags, int32_t *info, void *stream);
+
+/* ---------------------------------------------------------------------------------
  * bg_ann_rom_run -- batched replacement of FEMBurgers.pod_ann_prom, the WHOLE time loop on the device
  *   reference: FEM/fem_burgers.py:1177-1251 (loop), compute_ann_jacobian :1254-1275, model POD-ANN/pod_ann.py:38-56.
  *   One workgroup owns one sample for all time steps and Gauss-Newton iterations: assembly, fp64-MFMA projection of the

@@ -344,9 +344,10 @@ def quad_r40(hip):
 
 
 def test_config4_quadratic_r40_k820(hip, quad_r40):
-    """BASELINE configs[3]: quadratic manifold n = 40 (k = 820), 1024 samples per GPU: quad_tangent_kernel<8,40> +
-    rom_reduce4_kernel<8,10> on per-sample fragment-major tangents, persistent loop.  The decode GEMMs run through
-    rocBLAS, whose summation order may depend on the batch size, so chunks are compared to 1e-11 (not bitwise)."""
+    """BASELINE configs[3]: quadratic manifold n = 40 (k = 820), 1024 samples per GPU, through the device-side loop
+    bg_quad_rom_run (four samples per workgroup, 256 groups).  Every contraction of that path has a fixed summation
+    order, so the same call split into chunks is compared BITWISE (round 2 compared to 1e-11 and blamed the decode
+    GEMM's batch-size-dependent order for differing Galerkin counts: with the library GEMM gone the counts agree)."""
     from burgers_hip import rom
     X, Phi, H = quad_r40
     assert Phi.shape == (512, 40) and H.shape == (512, 820)
@@ -358,25 +359,29 @@ def test_config4_quadratic_r40_k820(hip, quad_r40):
         h2, it2, fl2 = _chunked(lambda lo, hi: rom.quadratic_run(X, np.ones(512), mu1[lo:hi], mu2[lo:hi], 0.05, nT, Phi, H,
                                                                  projection=proj), B)
         torch.cuda.synchronize()
+        assert hasattr(res, "info")                            # the device-side loop
+        assert torch.equal(res.iters, it2) and torch.equal(res.flags, fl2) and torch.equal(res.hist, h2), proj
         # LSPG (the reference's default, :1081) converges on every sample.  Galerkin with 40 quadratic modes does
         # not: most samples run into the 25-iteration cap ("Newton did not converge", :1171) and a non-convergent
-        # Newton path amplifies rounding differences, so there the comparison covers the samples that converged.
-        ok = (res.flags == 0) & (fl2 == 0)
+        # Newton path amplifies rounding differences, so there the oracle comparison covers the samples that converged.
+        ok = res.flags == 0
         if proj == "LSPG":
             assert bool(ok.all())
         assert int(ok.sum().item()) >= 16, proj
-        assert torch.equal(res.iters[ok], it2[ok]), proj
         # The Galerkin samples that do converge need 20-25 Newton iterations in the first step: a barely contractive path that
-        # amplifies a 1e-16 rounding difference (decode GEMM at another batch size, another summation order in the tangent)
-        # by up to 1e8 -- measured 3e-8 against the oracle on such samples, 6e-14 on the LSPG ones.
-        tol_chunk, tol_oracle = (1e-11, 1e-9) if proj == "LSPG" else (1e-6, 1e-6)
-        assert float((res.hist[ok] - h2[ok]).abs().max()) < tol_chunk * float(h2.abs().max()), proj
+        # amplifies a 1e-16 rounding difference by up to 1e8 -- measured 3e-8 against the oracle on such samples.
+        tol_oracle = 1e-10 if proj == "LSPG" else 1e-6
         probe = torch.nonzero(ok).flatten().cpu().numpy()
         for b in probe[np.linspace(0, len(probe) - 1, 4).astype(int)]:
             U, ito = br.pod_quadratic_manifold(X, 0.05, nT, np.ones(512), mu1[b], 0.0, mu2[b], Phi, H, projection=proj,
                                                return_iters=True)
-            assert rel_l2(res.hist[b].cpu().numpy().T, U) < tol_oracle, (proj, b)  # cond(H-augmented tangent) amplifies rounding
+            assert rel_l2(res.hist[b].cpu().numpy().T, U) < tol_oracle, (proj, b)
             assert np.array_equal(res.iters[b].cpu().numpy(), ito), (proj, b)
+        if proj == "LSPG":                                     # the host-driven batched path stays pinned at this shape too
+            bt = rom.quadratic_run(X, np.ones(512), mu1[:300], mu2[:300], 0.05, 2, Phi, H, projection=proj, fused=False)
+            torch.cuda.synchronize()
+            assert torch.equal(bt.iters, res.iters[:300, :2])
+            assert rel_l2(bt.hist.cpu().numpy(), res.hist[:300, :3].cpu().numpy()) < 1e-11
 
 
 def _ann_model(g):
