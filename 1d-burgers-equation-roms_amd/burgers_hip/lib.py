@@ -28,6 +28,7 @@ BG_ERR_WORKSPACE = -7
 BG_PROJ_GALERKIN, BG_PROJ_LSPG = 0, 1
 BG_FLAG_HIT_CAP, BG_FLAG_NONFINITE = 1, 2
 BG_OPT_SUPG, BG_OPT_NONUNIFORM, BG_OPT_W_COLMAJOR, BG_OPT_MFMA_16X16, BG_OPT_FORCE_PIVOTED, BG_OPT_NO_TANGENT_REUSE = 1, 2, 4, 8, 16, 32
+BG_OPT_FOM_WIDE, BG_OPT_FOM_WAVE = 64, 128
 BG_ACT_NONE, BG_ACT_ELU, BG_ACT_RELU, BG_ACT_TANH = 0, 1, 2, 3
 BG_COUNTER_SLOTS, BG_COUNTER_STRIDE = 16, 32
 BG_RBF_GAUSSIAN, BG_RBF_IMQ = 0, 1

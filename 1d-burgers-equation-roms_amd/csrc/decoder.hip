@@ -7,8 +7,8 @@
 // The product is write-bound (8 N bytes per column against 2 n N flops at n = 160): a library bf16 GEMM followed by a cast
 // writes the result twice (bf16, then float64) and reads it once more, 10 N + 2 N bytes per column instead of 8 N.
 // Workgroup = 128 columns x all N rows: the columns' coefficients sit in LDS (40 KB at n = 160), a wave takes every fourth
-// 32-row tile, its A fragments (U_modes rows, L2-resident) in registers, and stores each accumulator row as 32 consecutive
-// doubles of a sample's time axis.
+// 32-row tile, its A fragments (U_modes rows, L2-resident) in registers, and writes the tile through a per-wave LDS staging
+// block as runs of 128 consecutive doubles of a sample's time axis (1 KB per row, 16 bytes per lane).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,8 +30,14 @@ __global__ __launch_bounds__(256, 2) void decode_modes_kernel(const uint16_t* __
                                                            double* __restrict__ out, int N, int Nt, long long C)
 {
     constexpr int n = 16 * KB, LD = n + 8;                       // LDS row stride in bf16: 16-byte aligned, conflict-light
-    extern __shared__ __attribute__((aligned(16))) uint16_t s_q[];   // [DEC_COLS][LD]
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_q[];   // [DEC_COLS][LD], then the per-wave staging rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // Staging: 8 result rows x 128 columns of float64 per wave.  The accumulators of a 32 x 32 MFMA tile hold, per lane, ONE
+    // column and sixteen rows: stored as they stand, an instruction writes two 256-byte pieces with 8 bytes per lane (round 2:
+    // 3.0 TB/s).  Through LDS a wave turns eight rows of all four sub-tiles into eight runs of 1024 contiguous bytes along
+    // the time axis, 16 bytes per lane (the row pitch Nt * 8 = 4008 bytes leaves the runs 8-byte aligned only; the hardware
+    // splits the few lanes that straddle a line).
+    double* stage = reinterpret_cast<double*>(s_q + DEC_COLS * LD) + w * (8 * DEC_COLS);
     const long long c0 = (long long)blockIdx.x * DEC_COLS;
     // the workgroup's coefficient rows (zero beyond the last column)
     for (int e = tid; e < DEC_COLS * (n / 8); e += 256) {
@@ -43,17 +49,15 @@ __global__ __launch_bounds__(256, 2) void decode_modes_kernel(const uint16_t* __
     // operand lanes of v_mfma_f32_32x32x16_bf16: lane l holds row (A) / column (B) l % 32, k = 8 (l / 32) .. + 7;
     // result: acc[v] = D[8 (v / 4) + 4 (l / 32) + v % 4][l % 32]
     const int lr = lane & 31, lh = lane >> 5;
-    // output addresses of this lane's column in each 32-column sub-tile (a column is one (sample, time level) pair)
-    long long obase[DEC_COLS / 32];
-    bool live[DEC_COLS / 32];
-#pragma unroll
-    for (int ts = 0; ts < DEC_COLS / 32; ++ts) {
-        const long long c = c0 + 32 * ts + lr;
-        live[ts] = c < C;
-        const long long b = (live[ts] ? c : 0) / Nt;
-        const int t = (int)((live[ts] ? c : 0) - b * Nt);
-        obase[ts] = b * (long long)N * Nt + t;
+    // write-out role: lane l owns columns 2 l, 2 l + 1 of the workgroup's 128 (a column is one (sample, time level) pair)
+    long long o0, o1;                       // element offsets of the two columns at row 0 (-1: beyond the last column)
+    {
+        const long long ca = c0 + 2 * lane, cb = ca + 1;
+        const long long ba = (ca < C ? ca : 0) / Nt, bb = (cb < C ? cb : 0) / Nt;
+        o0 = ca < C ? ba * (long long)N * Nt + (ca - ba * Nt) : -1;
+        o1 = cb < C ? bb * (long long)N * Nt + (cb - bb * Nt) : -1;
     }
+    const bool pair = o0 >= 0 && o1 == o0 + 1;      // both columns in the same sample: one 16-byte store per row
     __syncthreads();
     for (int it = w; it < N / 32; it += 4) {
         const int i0 = 32 * it;
@@ -61,25 +65,40 @@ __global__ __launch_bounds__(256, 2) void decode_modes_kernel(const uint16_t* __
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
             a[kb] = *reinterpret_cast<const bf16x8*>(Um + (size_t)(i0 + lr) * n + 16 * kb + 8 * lh);
+        f32x16 acc[DEC_COLS / 32];
 #pragma unroll
         for (int ts = 0; ts < DEC_COLS / 32; ++ts) {
-            f32x16 acc;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+            for (int v = 0; v < 16; ++v) acc[ts][v] = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const bf16x8 bq = *reinterpret_cast<const bf16x8*>(&s_q[(32 * ts + lr) * LD + 16 * kb + 8 * lh]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb], bq, acc, 0, 0, 0);
+                acc[ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb], bq, acc[ts], 0, 0, 0);
             }
-            if (live[ts]) {
-                double* dst = out + obase[ts];
+        }
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int i = i0 + 8 * (v >> 2) + 4 * lh + (v & 3);
-                    dst[(size_t)i * Nt] = (double)acc[v];          // (non-temporal stores measured 25 % slower)
+        for (int v4 = 0; v4 < 4; ++v4) {             // rows i0 + 8 v4 .. + 7 of all 128 columns
+#pragma unroll
+            for (int ts = 0; ts < DEC_COLS / 32; ++ts) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    stage[(4 * lh + e) * DEC_COLS + 32 * ts + lr] = (double)acc[ts][4 * v4 + e];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const double2 val = *reinterpret_cast<const double2*>(&stage[r * DEC_COLS + 2 * lane]);
+                const long long ro = (long long)(i0 + 8 * v4 + r) * Nt;
+                if (pair) {
+                    *reinterpret_cast<double2*>(out + o0 + ro) = val;       // 8-byte aligned: see above
+                } else {
+                    if (o0 >= 0) out[o0 + ro] = val.x;
+                    if (o1 >= 0) out[o1 + ro] = val.y;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);       // one sub-tile at a time: interleaving all four costs 200 more registers
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -87,8 +106,20 @@ __global__ __launch_bounds__(256, 2) void decode_modes_kernel(const uint16_t* __
 template <int KB>
 int launch_decode(const uint16_t* Um, const uint16_t* Q, double* out, int N, int Nt, long long C, hipStream_t st)
 {
-    const size_t lds = (size_t)DEC_COLS * (16 * KB + 8) * sizeof(uint16_t);
+    const size_t lds = (size_t)DEC_COLS * (16 * KB + 8) * sizeof(uint16_t) + 4 * 8 * DEC_COLS * sizeof(double);
     const long long grid = (C + DEC_COLS - 1) / DEC_COLS;
+    if (lds > 64 * 1024) {                   // beyond the default dynamic-LDS limit: raise it once per instantiation and device
+        static std::atomic<unsigned> done{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned bit = 1u << (dev & 31);
+        if (!(done.load(std::memory_order_relaxed) & bit)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_modes_kernel<KB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return check_launch() == BG_OK ? BG_ERR_LAUNCH : BG_ERR_LAUNCH;
+            done.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
     hipLaunchKernelGGL((decode_modes_kernel<KB>), dim3((unsigned)grid), dim3(256), lds, st, Um, Q, out, N, Nt, C);
     return check_launch();
 }

@@ -331,9 +331,15 @@ int rows_per_lane(int N)
 // rows per lane the wave kernel still wins (N = 1536: 2.7e8 against 1.4e8).
 constexpr int kWaveMaxN = 64 * 24, kWideMaxN = WIDE_THREADS * 32;
 
+// Instantiations at 2 or 4 rows per thread (round 3) put a sample of N <= 512, 1024 nodes on all four SIMDs of a CU instead
+// of on one wavefront: built as the low-latency form for small batches (the strong-scaling share of a sweep, the
+// reference's one-mu-per-call pattern, FEM/paper_training_stage.py:28-49), measured slower than the wavefront form
+// (see bg_fom_run) and therefore opt-in (BG_OPT_FOM_WIDE).
 template <typename F>
 int dispatch_wide(int N, F&& f)
 {
+    if (N <= WIDE_THREADS * 2) return f(std::integral_constant<int, 2>{});     // (N <= 256: identity rows beyond N)
+    if (N <= WIDE_THREADS * 4) return f(std::integral_constant<int, 4>{});
     if (N <= WIDE_THREADS * 8) return f(std::integral_constant<int, 8>{});
     if (N <= WIDE_THREADS * 12) return f(std::integral_constant<int, 12>{});
     if (N <= WIDE_THREADS * 16) return f(std::integral_constant<int, 16>{});
@@ -401,13 +407,22 @@ int bg_fom_run(int N, int B, int nsteps, const double* x, const double* u0, cons
     const bool nonuniform = (supg & BG_OPT_NONUNIFORM) != 0;
     const dim3 grid((B + WAVES_PER_WG - 1) / WAVES_PER_WG), block(64 * WAVES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
-    if (N > kWaveMaxN)                // one workgroup per sample
+    // one workgroup per sample: beyond one wavefront's registers -- and, on request (BG_OPT_FOM_WIDE, uniform mesh, N > 64),
+    // below that too.  It is NOT the default there: measured at N = 1024 (round 3, B = 128 = one sample per second CU)
+    // 2.18 us per Picard iteration against 1.86 us for one wavefront per sample -- 4 rows per thread instead of 16 shorten
+    // the per-thread work threefold, but the seven workgroup barriers and LDS exchanges of an iteration cost more than that.
+    const bool both = N <= kWaveMaxN && N > 64 && !nonuniform;
+    const bool wide = N > kWaveMaxN || (both && (supg & BG_OPT_FOM_WIDE) && !(supg & BG_OPT_FOM_WAVE));
+    if (wide)
         return dispatch_wide(N, [&](auto rc) {
             constexpr int R = decltype(rc)::value;
-            if (nonuniform)
-                hipLaunchKernelGGL((fom_wide_kernel<R, false>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
-            else
-                hipLaunchKernelGGL((fom_wide_kernel<R, true>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
+            if constexpr (R >= 8) {
+                if (nonuniform) {
+                    hipLaunchKernelGGL((fom_wide_kernel<R, false>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
+                    return check_launch();
+                }
+            }
+            hipLaunchKernelGGL((fom_wide_kernel<R, true>), dim3(B), dim3(WIDE_THREADS), 0, st, a);
             return check_launch();
         });
     return dispatch_r(N, [&](auto rc) {

@@ -213,22 +213,20 @@ __global__ __launch_bounds__(256, 1) void quad_fused_kernel(QuadRunArgs a)
             while (true) {
                 ++npass;
                 // ---- pass start: publish q and the activity flag, seed u with Phi q ----------------------------------
-#pragma unroll
-                for (int i = 0; i < QCH; ++i) load_tile(0, i, av[i], tphi[i]);      // the first tiles stream in under Phi q
                 if (lane < QN) s_q[w][lane] = q;
                 if (lane == 0) s_act[w] = act ? 1 : 0;
                 {
                     double p[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                    for (int c0 = 0; c0 < QN; c0 += 4) {        // four columns (32 loads) in flight; PhiT rows beyond n are zero
-                        double f[4][8];
+                    for (int c0 = 0; c0 < QN; c0 += 8) {        // eight columns (64 loads) in flight; PhiT rows beyond n are zero
+                        double f[8][8];
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) {
+                        for (int cc = 0; cc < 8; ++cc) {
                             const double* pc = a.PhiT + (size_t)(c0 + cc) * NPAD + lane;
 #pragma unroll
                             for (int m = 0; m < 8; ++m) f[cc][m] = (64 * m < NPAD) ? pc[64 * m] : 0.0;
                         }
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) {
+                        for (int cc = 0; cc < 8; ++cc) {
                             const double qc = readlane_f64(q, c0 + cc);
 #pragma unroll
                             for (int m = 0; m < 8; ++m) p[m] = __builtin_fma(f[cc][m], qc, p[m]);
@@ -237,6 +235,8 @@ __global__ __launch_bounds__(256, 1) void quad_fused_kernel(QuadRunArgs a)
 #pragma unroll
                     for (int m = 0; m < 8; ++m) s_u[w][2 + lane + 64 * m] = p[m];
                 }
+#pragma unroll
+                for (int i = 0; i < QCH; ++i) load_tile(0, i, av[i], tphi[i]);      // the first tangent tiles of the pass
                 lap(0);
                 __syncthreads();
                 lap(5);

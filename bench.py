@@ -63,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--dt", type=float, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU-baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (the driver's contract): --batch samples PER GPU; strong: --batch is the GLOBAL sweep, split "
+                         "evenly over the ranks (each rank's share may then take the low-latency workgroup-per-sample kernel)")
     ap.add_argument("--other-configs", choices=("auto", "full", "small", "none"), default="auto",
                     help="1-GPU fom run: append short runs of BASELINE configs[2..4] as other_configs.  auto = full for the "
                          "driver's default command line, none once a workload flag is given; small = 96 samples x 12 steps "
@@ -199,6 +202,10 @@ class Workload:
     def __init__(self, args, rank, world, dev):
         import numpy as np
         self.args, self.rank, self.world, self.dev = args, rank, world, dev
+        if args.scaling == "strong" and not getattr(args, "_split", False):
+            if args.batch % world:
+                raise SystemExit(f"--scaling strong: --batch {args.batch} does not split evenly over {world} ranks")
+            args.global_batch, args.batch, args._split = args.batch, args.batch // world, True
         self.mu1, self.mu2 = mu_shard(args.batch, world, rank)
         self.X = np.linspace(0.0, 100.0, args.n)
         self.extra = {}
@@ -736,7 +743,7 @@ def _run_rank(args, real_stdout):
         par, cpu = cpu_leg(w, res, timed=(args.gpus == 1 and not args.no_cpu_baseline))
         line = {"metric": metric, "value": value, "unit": w.unit, "n_gpus": args.gpus, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": w.dtype, "data": "synthetic",
+                "scaling": args.scaling, "vs_baseline": None, "dtype": w.dtype, "data": "synthetic",
                 "config": {"workload": workload, "global_batch": args.batch * args.gpus,
                            "parallelism": "mu-shard x%d, no data-path collective" % args.gpus,
                            "units_per_pass": total_units, "seed": SEED},

@@ -48,7 +48,9 @@ enum { BG_OPT_SUPG = 1,        /* include the SUPG vector (fom_burgers, pod_prom
        BG_OPT_W_COLMAJOR = 4,  /* bg_rom_reduce*: W is [r][N] (per sample), not [N][r]             */
        BG_OPT_MFMA_16X16 = 8,  /* bg_rom_reduce*: use the v_mfma_f64_16x16x4 kernel for every r (A/B timing, tests) */
        BG_OPT_FORCE_PIVOTED = 16, /* bg_rom_run: take the partial-pivoting branch of the reduced solve every time (tests) */
-       BG_OPT_NO_TANGENT_REUSE = 32 /* bg_ann_rom_run: evaluate the closure at every step start even when its float32 input is unchanged (tests) */ };
+       BG_OPT_NO_TANGENT_REUSE = 32, /* bg_ann_rom_run: evaluate the closure at every step start even when its float32 input is unchanged (tests) */
+       BG_OPT_FOM_WIDE = 64,   /* bg_fom_run: one WORKGROUP per sample also for 64 < N <= 1536 (uniform mesh); measured slower than the default there */
+       BG_OPT_FOM_WAVE = 128   /* bg_fom_run: one WAVEFRONT per sample (the default for N <= 1536; overrides BG_OPT_FOM_WIDE) */ };
 
 /* transient value of bg_rom_run's info[b] between its two kernels (never seen by the caller) */
 #define BG_INFO_NEEDS_PIVOTING (-1)

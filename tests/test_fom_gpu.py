@@ -14,10 +14,23 @@ TOL = 1e-10
 
 
 def _run(hip, X, u0, mu1, mu2, dt, nsteps, **kw):
+    """fom_run in the form the library picks AND, where both forms exist (64 < N <= 1536: one wavefront or one workgroup
+    per sample), in each of them explicitly: they must agree (same iteration counts; the norms are summed in a different order, hence 1e-12 not bitwise).
+    Returns the library's own choice."""
     from burgers_hip import fom
     res = fom.fom_run(X, u0, mu1, mu2, dt, nsteps, **kw)
     torch.cuda.synchronize()
-    return res.hist.cpu().numpy(), res.iters.cpu().numpy(), res.flags.cpu().numpy()
+    out = res.hist.cpu().numpy(), res.iters.cpu().numpy(), res.flags.cpu().numpy()
+    if 64 < len(X) <= 1536 and "form" not in kw and "options" not in kw and not kw.get("trace"):
+        for form in ("wide", "wave"):
+            r2 = fom.fom_run(X, u0, mu1, mu2, dt, nsteps, form=form, **kw)
+            torch.cuda.synchronize()
+            assert np.array_equal(r2.iters.cpu().numpy(), out[1]) and np.array_equal(r2.flags.cpu().numpy(), out[2]), form
+            h2 = r2.hist.cpu().numpy()
+            fin = np.isfinite(out[0]) & np.isfinite(h2)
+            assert np.array_equal(np.isfinite(out[0]), np.isfinite(h2)), form
+            assert np.abs(h2[fin] - out[0][fin]).max() <= 1e-12 * max(1.0, np.abs(out[0][fin]).max()), form
+    return out
 
 
 def test_cross_lane_primitives_via_tridiag_solve(hip):
@@ -335,6 +348,26 @@ def test_workgroup_wide_tridiag_solve(hip):
         sol = fom.tridiag_solve(*[torch.tensor(a, device="cuda") for a in (lo, di, up, rhs)]).cpu().numpy()
         for b in range(B):
             assert rel_l2(sol[b], br.tridiag_solve(lo[b], di[b], up[b], rhs[b])) < 1e-12, f"N={N}"
+
+
+@pytest.mark.parametrize("N,B", [(1024, 128), (1024, 1), (512, 256), (256, 7), (777, 33), (1300, 5), (65, 3)])
+def test_low_latency_form(hip, N, B):
+    """The workgroup-per-sample kernels at 2 / 4 / 8 rows per thread (N <= 512 / 1024 / 1536), built as a low-latency
+    form for small batches (form="wide"; measured slower than one wavefront per sample, hence opt-in): against the C
+    oracle and the wavefront form."""
+    from burgers_hip import fom
+    rng = np.random.default_rng(N + B)
+    mu1 = rng.uniform(4.25, 5.5, B); mu2 = rng.uniform(0.015, 0.03, B)
+    X = np.linspace(0.0, 100.0, N)
+    dt = 0.05 * 512 / max(N, 512)
+    rw = fom.fom_run(X, np.ones(N), mu1, mu2, dt, 12, E=0.001, form="wide")
+    rv = fom.fom_run(X, np.ones(N), mu1, mu2, dt, 12, E=0.001, form="wave")
+    rd = fom.fom_run(X, np.ones(N), mu1, mu2, dt, 12, E=0.001)
+    torch.cuda.synchronize()
+    ho, ito = bc.fom_run(X, np.ones(N), mu1, mu2, dt, 12, E=0.001)
+    for r in (rw, rv, rd):
+        assert rel_l2(r.hist.cpu().numpy(), ho) < TOL and np.array_equal(r.iters.cpu().numpy(), ito)
+    assert torch.equal(rd.hist, rv.hist)                     # the default is the wavefront form (bit for bit)
 
 
 @pytest.mark.parametrize("N", WIDE_SIZES)
