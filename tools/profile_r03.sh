@@ -1,0 +1,43 @@
+#!/bin/bash
+# Round-3 evidence in one GPU call, condensed ON the box into gpurun_out/r03_profiles/ (copy its files into profiles/):
+#   1. rocprofv3 --kernel-trace --stats of the DEFAULT bench.py command (FOM headline + the other_configs runs)
+#   2. per ROM config (short passes): one SQ pass (matrix-pipe / VALU activity), one FETCH_SIZE pass, one WRITE_SIZE pass
+#      (counters in their own passes, no trace domains besides --kernel-trace: MI355X_MICROARCH, rocprofv3 PMC slots)
+set -e
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r03_profiles
+W=/tmp/r03_prof
+rm -rf $W; mkdir -p $O $W
+cd /tmp
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $W/kt -- python $R/bench.py --no-cpu-baseline > $W/kt.log 2>&1
+f=$(ls $W/kt/*/*kernel_stats.csv | head -1)
+python3 - "$f" "$O/r03_default_bench_kernel_stats.csv" <<'PY'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+with open(sys.argv[2], "w", newline="") as g:
+    w = csv.writer(g); w.writerow(rows[0])
+    for r in rows[1:26]:
+        w.writerow([r[0][:120]] + r[1:])
+PY
+grep -h '"metric"' $W/kt.log | tail -1 > $O/r03_bench_default_under_profiler.json || true
+echo "kernel trace done"
+for cfg in ${CONFIGS:-pod_galerkin pod_lspg quadratic ann}; do
+  case $cfg in
+    pod_*) key="rom_fused_kernel"; ts=40;;
+    quadratic) key="quad_fused_kernel"; ts=40;;
+    ann) key="rom_ann_fused_kernel"; ts=40;;
+  esac
+  mkdir -p $W/$cfg
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $W/$cfg/sq -- python $R/bench.py --config $cfg --steps 1 --warmup 1 --time-steps $ts --no-cpu-baseline > $W/$cfg/sq.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $W/$cfg/fetch -- python $R/bench.py --config $cfg --steps 1 --warmup 1 --time-steps $ts --no-cpu-baseline > $W/$cfg/fetch.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $W/$cfg/write -- python $R/bench.py --config $cfg --steps 1 --warmup 1 --time-steps $ts --no-cpu-baseline > $W/$cfg/write.log 2>&1
+  python3 $R/tools/summarize_pmc.py $W/$cfg $key > $O/r03_${cfg}_pmc.json
+  grep -h '"metric"' $W/$cfg/sq.log | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(json.dumps({k: d[k] for k in ('value','ms_per_step','steps') } | {'units_per_pass': d['config']['units_per_pass'], 'workload': d['config']['workload']}))" > $O/r03_${cfg}_bench_under_sq_pass.json || true
+  echo "$cfg done"; cat $O/r03_${cfg}_pmc.json | head -60
+done
+rm -rf $W
+ls -la $O
