@@ -152,11 +152,20 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
     auto& s_act = *reinterpret_cast<float (*)[2][ANN_MAX_ROWS][ANN_MAX_WIDTH]>(s_shared);   // MLP activations: value row + n tangent rows
     auto& s_dN = *reinterpret_cast<double (*)[kModes][kBS]>(s_shared + kActB);              // mode j of the sweep: [d(coefficient j)/dq_p | coefficient j | 0]
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int t = lane & 3, owner = 16 * w + (lane >> 2);
+    // The thread-index family is re-derived from an opaque copy at the top of every Gauss-Newton pass (see the time loop):
+    // per-lane addresses are loop invariants of the whole kernel, and hoisted out of the loops by the dozen they end up in
+    // scratch (round 3: the same measure took bg_rom_run's kernels from 160 / 280 to 12 / 152 bytes).
+    int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction
+    int t = lane & 3, owner = 16 * w + (lane >> 2);
     const int N = a.N, n = a.n, nbar = a.nbar, nr = 1 + a.n, m8 = (a.n + a.nbar + 7) & ~7;
     const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
-    const int rowbase = owner * S;
+    int rowbase = owner * S;
+    auto rederive = [&]() {
+        int v = threadIdx.x;
+        asm volatile("" : "+v"(v));
+        tid = v; lane = v & 63; t = lane & 3; owner = 16 * w + (lane >> 2); rowbase = owner * S;
+    };
 
     if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;
     for (int e = tid; e < (NPAD + 2) * RW; e += 256) (&s_W[0][0])[e] = 0.0;
@@ -562,6 +571,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
             int k = 0;
             bool more = true, decode = false;
             while (true) {
+                rederive();
                 // ---- closure at the current q_p (one call site: the code is inlined once).  First pass of a time step:
                 // dN at the first guess (:1219), tangent only, U0 stays u^n.  Later passes: q_s = N(q_p) for the decode
                 // (:1241-1242) and dN for the next projection (:1219-1224).

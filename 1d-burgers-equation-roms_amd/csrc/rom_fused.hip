@@ -67,7 +67,10 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
 #define BG_ACC_BUDGET (((256 - 2 * S * NB - 56) / 2) < 24 ? ((256 - 2 * S * NB - 56) / 2) : 24)
 #endif
     // accumulators a pass may keep live: what 256 registers leave beside the 2 S NB fragment registers and ~56 others (measured at r = 40, N = 512: 16 ... 24 accumulators run alike, 30 spill into the MFMA loop and lose 25 %)
-    constexpr int kAccBudget = PIV ? 64 : (BG_ACC_BUDGET);
+#ifndef BG_ACC_BUDGET_LSPG
+#define BG_ACC_BUDGET_LSPG (((256 - 2 * S * NB - 48) / 2) < 24 ? ((256 - 2 * S * NB - 48) / 2) : 24)   // LSPG keeps fewer operands live: 24 (measured 20: 1.64e7, 24 / 28: 1.68e7, 30: 1.59e7)
+#endif
+    constexpr int kAccBudget = PIV ? 64 : (GAL ? (BG_ACC_BUDGET) : (BG_ACC_BUDGET_LSPG));
 #ifndef BG_NRED
 #define BG_NRED 2
 #endif
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
     __shared__ int s_bad[4];
     __shared__ int s_info;
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction
     const int t = lane & 3, owner = 16 * w + (lane >> 2);
     const int N = a.N, r = a.r;
     const double h = (a.x[N - 1] - a.x[0]) / (double)(N - 1);
@@ -107,7 +111,6 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
             s_edge[1][c][w][t] = (ih < N && col < r) ? a.Phi[(size_t)ih * r + col] : 0.0;
         }
     }
-    const HaloLanes<NB> halo{s_edge, w, t, lane};
     if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;      // halos [0], [1], [NPAD+2], [NPAD+3]
 
     for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
@@ -181,6 +184,13 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
             bool more;
             lap(5);
             do {
+                // Per-lane addresses are loop invariants of this whole kernel; the optimiser hoists them out of the time loop by
+                // the dozen and then spills them.  An opaque copy of the thread index per iteration keeps them recomputed
+                // (a few integer instructions) instead: scratch 160 -> 76 bytes (Galerkin), 280 -> 140 (LSPG).
+                int tid_i = tid;
+                asm volatile("" : "+v"(tid_i));
+                const int lane = tid_i & 63, t = lane & 3, rowbase = (16 * w + (lane >> 2)) * S;
+                const HaloLanes<NB> halo{s_edge, w, t, lane};
                 // ---- assembly: A(u_k), R(u_k) per row into LDS ----------------------------------------------------
                 if (!skip(16))
                 for (int i = tid; i < NPAD; i += 256) {

@@ -80,35 +80,33 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const Hal
 #pragma unroll
     for (int p = 0; p < NACC; ++p) acc[p] = 0.0;
     // B operands of row step s: Y = (A Phi) rows, X = extra block [R, u, 0, 0]
-    auto operands = [&](int s, double (&Y)[NB], double& X) {
-        const int i = rowbase + s;
-        const double lo = s_coef[i][0], di = s_coef[i][1], up = s_coef[i][2], R = s_coef[i][3];
-        const double ui = s_u[i + 2];
-#pragma unroll
-        for (int c = (GAL ? CA0 : 0); c < (GAL ? CA1 : NB); ++c) {
-            const double below = (s == 0) ? halo(0, c, frag) : frag[c][s == 0 ? 0 : s - 1];
-            const double above = (s == S - 1) ? halo(1, c, frag) : frag[c][s == S - 1 ? s : s + 1];
-            double y = lo * below;
-            y = __builtin_fma(di, frag[c][s], y);
-            y = __builtin_fma(up, above, y);
-            Y[c] = y;
-        }
-        X = (t == 0) ? R : ((t == 1) ? ui : 0.0);
+    auto form_y = [&](int s, int c, double lo, double di, double up) -> double {
+        const double below = (s == 0) ? halo(0, c, frag) : frag[c][s == 0 ? 0 : s - 1];
+        const double above = (s == S - 1) ? halo(1, c, frag) : frag[c][s == S - 1 ? s : s + 1];
+        double y = lo * below;
+        y = __builtin_fma(di, frag[c][s], y);
+        return __builtin_fma(up, above, y);
     };
     // No software pipelining here: measured (tools/mfma_valu_bench.hip) the fp64 4x4x4 MFMA does not overlap with vector
     // ALU work of the same wave -- 110 MFMAs take 882 ns alone and 882 + 2.25 ns per interleaved v_fma_f64 -- so the
     // phase costs the MFMAs plus every other instruction; interleaving only adds hazard s_nops (498 against 103).
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        double Y[NB], X;
-        operands(skip(64) ? 0 : s, Y, X);        // (64: timing only)
-        int p = 0;
+        const int ss = skip(64) ? 0 : s;         // (64: timing only)
+        const int i = rowbase + ss;
+        const double lo = s_coef[i][0], di = s_coef[i][1], up = s_coef[i][2], R = s_coef[i][3];
+        const double ui = s_u[i + 2];
+        const double X = (t == 0) ? R : ((t == 1) ? ui : 0.0);
         if constexpr (GAL) {
+            double Y[CA1 - CA0];
+#pragma unroll
+            for (int c = CA0; c < CA1; ++c) Y[c - CA0] = form_y(ss, c, lo, di, up);
+            int p = 0;
 #pragma unroll
             for (int ca = 0; ca < NB; ++ca) {
 #pragma unroll
                 for (int cb = CA0; cb < CA1; ++cb, ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], Y[cb], acc[p], 0, 0, 0);
+                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], Y[cb - CA0], acc[p], 0, 0, 0);
             }
             if constexpr (LAST) {
 #pragma unroll
@@ -116,18 +114,38 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const Hal
                     acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], X, acc[p], 0, 0, 0);
             }
         } else {
+            // LSPG, pairs (ca in the pass's range, cb >= ca).  Only the range's own operands stay live; the columns beyond it
+            // are formed one at a time, used by every ca of the range and dropped (all NB - CA0 of them live at once spilled
+            // into the matrix loop: 2.8 GB of scratch re-fetches per 40-step launch against 0.07 GB for the Galerkin form)
+            constexpr int NA = CA1 - CA0;
+            auto pidx = [](int ca, int cb) {         // as for_each_acc enumerates them: ca major, cb = ca .. NB
+                int p = 0;
+                for (int c = CA0; c < ca; ++c) p += NB - c + 1;
+                return p + (cb - ca);
+            };
+            double Ya[NA];
+#pragma unroll
+            for (int ca = CA0; ca < CA1; ++ca) Ya[ca - CA0] = form_y(ss, ca, lo, di, up);
 #pragma unroll
             for (int ca = CA0; ca < CA1; ++ca) {
 #pragma unroll
-                for (int cb = ca; cb < NB; ++cb, ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(Y[ca], Y[cb], acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(Y[ca], X, acc[p], 0, 0, 0);
-                ++p;
+                for (int cb = ca; cb < CA1; ++cb)
+                    acc[pidx(ca, cb)] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ya[ca - CA0], Ya[cb - CA0], acc[pidx(ca, cb)], 0, 0, 0);
             }
+#pragma unroll
+            for (int cb = CA1; cb < NB; ++cb) {
+                const double Yb = form_y(ss, cb, lo, di, up);
+#pragma unroll
+                for (int ca = CA0; ca < CA1; ++ca)
+                    acc[pidx(ca, cb)] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ya[ca - CA0], Yb, acc[pidx(ca, cb)], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ca = CA0; ca < CA1; ++ca)
+                acc[pidx(ca, NB)] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ya[ca - CA0], X, acc[pidx(ca, NB)], 0, 0, 0);
             if constexpr (LAST) {
 #pragma unroll
-                for (int ca = 0; ca < NB; ++ca, ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], X, acc[p], 0, 0, 0);
+                for (int ca = 0; ca < NB; ++ca)
+                    acc[NROW + ca] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], X, acc[NROW + ca], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);       // nothing moves across a step: bounded register pressure
@@ -303,6 +321,9 @@ __device__ __forceinline__ double coop_gj_solve(const double (*__restrict__ s_re
 {
     constexpr int RW = 4 * NB;
     constexpr int NSLOT = LuRegs<NB>::NSLOT;
+    // `lane` is made opaque here: the per-lane LDS addresses and mirror selects of the load below are loop invariants, and
+    // left to itself the optimiser hoists them out of the time loop and keeps (or spills) two dozen registers for them
+    asm volatile("" : "+v"(lane));
     auto entry = [&](int i, int j) -> double {               // (Ar | br)[i][j], j <= RW
         int rr = i, cc = j;
         if (!GAL && j < RW && (i >> 2) > (j >> 2)) { rr = j; cc = i; }   // LSPG: mirror the lower blocks
