@@ -88,6 +88,11 @@ _SIGNATURES = {
                                        c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p,
                                        ctypes.c_void_p]),
+    "bg_rom_run_wide_max_r": (ctypes.c_int, []),
+    "bg_rom_run_wide_phi_elems": (ctypes.c_longlong, [ctypes.c_int]),
+    "bg_rom_run_wide": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                       c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
     "bg_rom_lift": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                    c_int_p, c_double_p, ctypes.c_void_p]),
     "bg_quad_features": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_double_p, ctypes.c_void_p]),

@@ -279,6 +279,49 @@ def pod_prom_run_fused(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E=0.0, tol=1e-6, 
     return res
 
 
+def pod_prom_run_wide(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E=0.0, tol=1e-6, max_it=20, device=None, PhiP=None, options=0):
+    """``pod_prom_burgers`` for bases of 41 .. 96 modes with the whole time loop on the device (bg_rom_run_wide): the basis
+    streams through LDS, the reduced system's accumulators are spread over the four waves of the sample's workgroup.
+    Samples whose elimination would have needed a row exchange come back marked and are redone through the library
+    path (LU with partial pivoting).  ``PhiP``: the padded basis copy of a previous call (``res.PhiP``) to reuse."""
+    L = _lib.load()
+    device = _lib.require_device(device)
+    opts = _lib.mesh_options(check_mesh(X), supg=True) | options
+    Xd = _as_dev(X, device)
+    N = Xd.numel()
+    Phid = _as_dev(Phi, device)
+    if Phid.dim() != 2 or Phid.shape[0] != N:
+        raise ValueError("Phi must have one row per mesh node")
+    r = Phid.shape[1]
+    if PhiP is None:
+        NPAD = (N + 63) // 64 * 64
+        PhiP = torch.zeros((NPAD + 2, 96), dtype=torch.float64, device=device)
+        PhiP[1:N + 1, :r] = Phid
+    assert PhiP.numel() == L.bg_rom_run_wide_phi_elems(N)
+    u0d, mu1d, mu2d = _batch_inputs(u0, mu1, mu2, N, device)
+    B = mu1d.numel()
+    hist = torch.empty((B, nsteps + 1, N), dtype=torch.float64, device=device)
+    iters = torch.zeros((B, nsteps), dtype=torch.int32, device=device)
+    flags = torch.zeros((B,), dtype=torch.int32, device=device)
+    info = torch.zeros((B,), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        rc = L.bg_rom_run_wide(N, B, r, int(nsteps), proj, _lib.ptr(Xd), _lib.ptr(PhiP), _lib.ptr(u0d), _lib.ptr(mu1d),
+                               _lib.ptr(mu2d), float(dt), float(E), float(tol), int(max_it), int(opts), _lib.ptr(hist),
+                               _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(info), _lib.stream_ptr(device))
+    _lib.check(rc, "bg_rom_run_wide")
+    redo = (info == _lib.BG_INFO_NEEDS_PIVOTING).nonzero().squeeze(1)
+    if redo.numel():                                     # rare: np.linalg.solve would have exchanged rows
+        rr = _pod_prom_run_library(Xd, u0d[redo], mu1d[redo], mu2d[redo], dt, nsteps, Phid, proj, E, tol, max_it, device)
+        hist[redo], iters[redo], flags[redo] = rr.hist, rr.iters, rr.flags
+        info[redo] = 0
+    res = FomResult(hist, iters, flags)
+    res.info = info
+    res.redone = int(redo.numel())
+    res.PhiP = PhiP
+    res._keep = (Xd, u0d, mu1d, mu2d)
+    return res
+
+
 def check_singular(res):
     """np.linalg.solve raises LinAlgError('Singular matrix') at :767; the device loop records it per sample."""
     info = getattr(res, "info", None)
@@ -297,6 +340,8 @@ def pod_prom_run(X, u0, mu1, mu2, dt, nsteps, Phi, projection="Galerkin", E=0.0,
     proj = PROJ[projection.lower()]
     L = _lib.load()
     r_in, n_in = np.shape(Phi)[1], np.shape(Phi)[0]
+    if fused and L.bg_rom_run_max_r() < r_in <= L.bg_rom_run_wide_max_r() and n_in <= 512:
+        return check_singular(pod_prom_run_wide(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E, tol, max_it, device))
     if r_in > L.bg_rom_max_r() or n_in > L.bg_rom_max_n():
         return _pod_prom_run_library(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E, tol, max_it, device)
     if fused and r_in <= L.bg_rom_run_max_r():

@@ -52,7 +52,8 @@ enum { BG_OPT_SUPG = 1,        /* include the SUPG vector (fom_burgers, pod_prom
        BG_OPT_FOM_WIDE = 64,   /* bg_fom_run: one WORKGROUP per sample also for 64 < N <= 1536 (uniform mesh); measured slower than the default there */
        BG_OPT_FOM_WAVE = 128   /* bg_fom_run: one WAVEFRONT per sample (the default for N <= 1536; overrides BG_OPT_FOM_WIDE) */ };
 
-/* transient value of bg_rom_run's info[b] between its two kernels (never seen by the caller) */
+/* bg_rom_run: transient value of info[b] between its two kernels (never seen by the caller);
+ * bg_rom_run_wide: info[b] of a sample the caller must redo with a pivoting solve */
 #define BG_INFO_NEEDS_PIVOTING (-1)
 
 /* per-sample status bits written to `flags` */
@@ -235,6 +236,24 @@ int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double *x,
                const double *u0, const double *mu1, const double *mu2, double dt, double E, double tol,
                int max_it, int options, double *hist, int32_t *iters, int32_t *flags, int32_t *info,
                void *stream);
+
+/* bg_rom_run_wide -- bg_rom_run for the thesis' larger bases, 40 < r <= 96 (bg_rom_run_wide_max_r), N <= 512
+ *   reference: FEM/fem_burgers.py:709-785 with POD/modes/U_modes_tol_1e-04.npy (r = 96), POD/Results_thesis/prom_pod.py:35-58.
+ *   Same arguments, outputs and semantics as bg_rom_run except:
+ *   PhiP   [NPAD + 2][96], NPAD = N rounded up to 64 (bg_rom_run_wide_phi_elems(N) doubles, 16-byte aligned): Phi row i at
+ *          row index i + 1, zero rows around and beyond the mesh, zero columns beyond r -- built once per basis by the caller;
+ *   info   0, k + 1 for an exactly singular reduced system, or BG_INFO_NEEDS_PIVOTING for a sample whose pivot-free
+ *          elimination met a multiplier above 1: the caller redoes that sample with a pivoting solve (there is no second
+ *          kernel here; burgers_hip/rom.py sends it through the library path).
+ *   The basis streams through LDS 64 mesh rows at a time, the accumulators of the reduced system are dealt to the four
+ *   waves (csrc/rom_wide.hip).  options: BG_OPT_SUPG | BG_OPT_NONUNIFORM | BG_OPT_FORCE_PIVOTED (tests: every sample is
+ *   handed back as if its elimination had needed a row exchange). */
+int bg_rom_run_wide_max_r(void);
+long long bg_rom_run_wide_phi_elems(int N);
+int bg_rom_run_wide(int N, int B, int r, int nsteps, int projection, const double *x, const double *PhiP,
+                    const double *u0, const double *mu1, const double *mu2, double dt, double E, double tol,
+                    int max_it, int options, double *hist, int32_t *iters, int32_t *flags, int32_t *info,
+                    void *stream);
 
 /* =================================================================================
  * bg_fd_run -- batched replacement of FDBurgers.fom_burgers_newton (analytical Jacobian)

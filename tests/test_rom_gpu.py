@@ -326,8 +326,9 @@ def test_pod_prom_large_basis_library_path(hip):
     X, _ = mesh(512)
     assert g["Phi"].shape == (512, 96)
     for tag, proj in (("galerkin", "Galerkin"), ("lspg", "LSPG")):
-        res = rom.pod_prom_run(X, np.ones(512), [4.75, 5.3], [0.02, 0.018], 0.05, 8, g["Phi"], projection=proj)
+        res = rom.pod_prom_run(X, np.ones(512), [4.75, 5.3], [0.02, 0.018], 0.05, 8, g["Phi"], projection=proj, fused=False)
         torch.cuda.synchronize()
+        assert not hasattr(res, "PhiP")                       # the library path (r = 96 defaults to bg_rom_run_wide since round 3)
         assert rel_l2(res.hist[0].cpu().numpy().T, g["first9_" + tag]) < TOL
         U, ito = br.pod_prom_burgers(X, 0.05, 8, np.ones(512), 5.3, 0.0, 0.018, g["Phi"], projection=proj, return_iters=True)
         assert rel_l2(res.hist[1].cpu().numpy().T, U) < TOL and np.array_equal(res.iters[1].cpu().numpy(), ito)
