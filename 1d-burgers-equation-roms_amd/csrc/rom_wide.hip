@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/burgers_hip.h"
 #include "abi_common.hpp"
 #include "rom_device.hpp"
@@ -125,13 +127,169 @@ __device__ __forceinline__ void wide_park(const double (&acc)[WideItems<GAL>::pe
     }
 }
 
+typedef __attribute__((address_space(3))) double lds_double_t;
+typedef __attribute__((address_space(3))) int lds_int_t;
+
+// The 96 x 96 solve of one iteration by all four waves: ONE out-of-line copy for every wave and both halves of the panel
+// range (the wave number and the panel are run-time values here).  Inlined into the four per-wave bodies and unrolled over
+// its 24 panels it was 160 KB of straight-line code per pass and CU -- four waves streaming four different copies through
+// the instruction cache -- and took longer than the projection (111 k of 218 k clocks per pass).
+// In: the parked system S (Ar | br, LSPG: upper blocks).  Out: s_diag, s_y (x_k = y_k / d_k), s_bad[w] = guard of this wave.
+// wave w owns the column blocks b = w, w + 4, ... (six of 24); the right-hand side rides with wave 3.
+// col[s][tile][tt] = entry (row 64 tile + lane, column 4 (w + 4 s) + tt).  Contains workgroup barriers: all waves call it.
+template <bool GAL>
+__device__ __attribute__((noinline)) void wide_solve(const lds_double_t* S, lds_double_t* s_m, lds_double_t* s_diag, lds_double_t* s_y,
+                                                     lds_int_t* s_bad, int w, int lane, int r)
+{
+    double col[6][2][4], rhs[2];
+    auto entry = [&](int i, int j) -> double {   // (Ar | br)[i][j]; LSPG: the lower blocks by symmetry
+        int rr = i, cc = j;
+        if (!GAL && j < WR && (i % 24) > (j % 24)) { rr = j; cc = i; }
+        return S[rr * WPS + cc];
+    };
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+        const int row = 64 * tile + lane;
+        const bool rin = row < WR;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int j = 4 * (w + 4 * s) + tt;
+                double v = 0.0;
+                if (rin) v = (row >= r || j >= r) ? ((row == j) ? 1.0 : 0.0) : entry(row, j);
+                col[s][tile][tt] = v;
+            }
+        }
+        rhs[tile] = (w == 3 && rin && row < r) ? -entry(row, WR) : 0.0;
+    }
+    double gmax = 0.0;
+    bool zero_piv = false;
+    // factor the panel p held in slot OS (pivot rows in row tile TK); multipliers of all 96 rows -> s_m[p & 1][kk][row]
+    auto factor = [&](int p, auto os_c, auto tk_c) {
+        constexpr int OS = decltype(os_c)::value, TK = decltype(tk_c)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kr = 4 * p + kk, lk = kr & 63;
+            const double piv = readlane_f64(col[OS][TK][kk], lk);
+            const double rp = rcp(piv);
+            zero_piv = zero_piv | (piv == 0.0);
+            double pvj[4];
+#pragma unroll
+            for (int jj = kk + 1; jj < 4; ++jj) pvj[jj] = readlane_f64(col[OS][TK][jj], lk);
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) {
+                const int row = 64 * tile + lane;
+                const double m = (row != kr && row < WR) ? col[OS][tile][kk] * rp : 0.0;    // rows above the pivot too
+                gmax = fmax(gmax, (row > kr) ? fabs(m) : 0.0);
+#pragma unroll
+                for (int jj = kk + 1; jj < 4; ++jj) col[OS][tile][jj] = __builtin_fma(-m, pvj[jj], col[OS][tile][jj]);
+                if (row < WR) s_m[((p & 1) * 4 + kk) * WR + row] = m;
+            }
+        }
+    };
+    // apply panel p (multipliers m, pivot rows in row tile TK) to the block in slot SL
+    auto apply = [&](int p, auto sl_c, auto tk_c, const double (&m)[4][2]) {
+        constexpr int SL = decltype(sl_c)::value, TK = decltype(tk_c)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int lk = (4 * p + kk) & 63;
+            double pv[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) pv[tt] = readlane_f64(col[SL][TK][tt], lk);
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) col[SL][tile][tt] = __builtin_fma(-m[kk][tile], pv[tt], col[SL][tile][tt]);
+        }
+    };
+    // `slot` is a run-time value: pick the register block with a (wave-uniform) switch
+    auto with_slot = [&](int slot, auto&& f) {
+        switch (slot) {
+            case 0: f(std::integral_constant<int, 0>{}); break;
+            case 1: f(std::integral_constant<int, 1>{}); break;
+            case 2: f(std::integral_constant<int, 2>{}); break;
+            case 3: f(std::integral_constant<int, 3>{}); break;
+            case 4: f(std::integral_constant<int, 4>{}); break;
+            default: f(std::integral_constant<int, 5>{}); break;
+        }
+    };
+    __syncthreads();                               // every wave has its columns: the parked system is dead
+    if (w == 0) factor(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    __syncthreads();
+    // One barrier per panel: while the other waves apply panel p to their later blocks, the owner of panel p + 1 brings that
+    // block up to date first, factors it and publishes its multipliers (look-ahead), then does the rest.
+    auto panels = [&](int p0, int p1, auto tk_c) {          // the pivots of panels [p0, p1) sit in row tile TK
+        constexpr int TK = decltype(tk_c)::value;
+#pragma unroll 1
+        for (int p = p0; p < p1; ++p) {
+            double m[4][2];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                m[kk][0] = s_m[((p & 1) * 4 + kk) * WR + lane];
+                m[kk][1] = (lane < WR - 64) ? s_m[((p & 1) * 4 + kk) * WR + 64 + lane] : 0.0;
+            }
+            const int nxt = p + 1;
+            if (nxt < WNB && (nxt & 3) == w) {
+                with_slot(nxt >> 2, [&](auto sl) {
+                    apply(p, sl, tk_c, m);
+                    if (nxt < 16) factor(nxt, sl, std::integral_constant<int, 0>{});
+                    else factor(nxt, sl, std::integral_constant<int, 1>{});
+                });
+            }
+            auto own = [&](auto sl) {                      // this wave's block in slot SL
+                const int b = w + 4 * decltype(sl)::value;
+                if (b > p && b != nxt) apply(p, sl, tk_c, m);
+            };
+            own(std::integral_constant<int, 0>{}); own(std::integral_constant<int, 1>{}); own(std::integral_constant<int, 2>{});
+            own(std::integral_constant<int, 3>{}); own(std::integral_constant<int, 4>{}); own(std::integral_constant<int, 5>{});
+            if (w == 3) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int lk = (4 * p + kk) & 63;
+                    const double pv = readlane_f64(rhs[TK], lk);
+                    rhs[0] = __builtin_fma(-m[kk][0], pv, rhs[0]);
+                    rhs[1] = __builtin_fma(-m[kk][1], pv, rhs[1]);
+                }
+            }
+            if (p + 1 < WNB) __syncthreads();
+        }
+    };
+    panels(0, 16, std::integral_constant<int, 0>{});
+    panels(16, WNB, std::integral_constant<int, 1>{});
+    // what is left is diagonal: x_k = y_k / d_k.  Publish d (the owner of each column) and y (wave 3).
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int j = 4 * (w + 4 * s) + tt;   // this column's diagonal entry sits in row j
+            if (lane == (j & 63)) s_diag[j] = (j >> 6) ? col[s][1][tt] : col[s][0][tt];
+        }
+    }
+    if (w == 3) {
+        s_y[lane] = rhs[0];
+        if (lane < WR - 64) s_y[64 + lane] = rhs[1];
+    }
+    {
+        const unsigned long long anybad = __ballot(zero_piv | !(gmax <= 1.0));
+        if (lane == 0) s_bad[w] = anybad != 0ull;
+    }
+    __syncthreads();
+}
+
+#ifdef BG_WIDE_TIMING                   // diagnostic builds (tools/time_wide_rom.py --phases): kilo-clocks per phase in place of the counts
+constexpr bool kWT = true;
+#else
+constexpr bool kWT = false;
+#endif
+
 struct WideLdsPtrs {
     double* slab;           // two slab buffers; later the system
     double* u;              // [NPADM + 4]
     double* g; double* h; double* fdt;      // [NPADM]
     double (*cf)[4];        // [NPADM][4]
     double* q;              // [WR]
-    double (*m)[WR];        // [4][WR]
+    double (*m)[WR];        // [2][4][WR]: multipliers of the current and the next panel
     double* diag; double* y;
     int* bad;
 };
@@ -200,6 +358,16 @@ __device__ __forceinline__ void rom_wide_body(const WideRunArgs& a, const WideLd
 
         int flags = 0, info_out = 0;
         bool aborted = false;
+        long long cyc[6] = {0, 0, 0, 0, 0, 0};
+        long long tick = kWT ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        int npass = 0;
+        auto lap = [&](int i) {
+            if constexpr (kWT) {
+                const long long now = (long long)__builtin_amdgcn_s_memtime();
+                cyc[i] += now - tick;
+                tick = now;
+            }
+        };
         // LDS DMA of slab `slab` (mesh rows [r0 - 1, r0 + 64] = rows r0 .. r0 + 65 of PhiP) into buffer `buf`: wave w moves the
         // 1-KB pieces w, w + 4, ...; a lane's 16 bytes land at piece base + 16 lane, i.e. LDS row o / 784, byte o % 784 of it
         // (the 16 bytes of row padding are filled from a valid dummy address)
@@ -249,12 +417,15 @@ __device__ __forceinline__ void rom_wide_body(const WideRunArgs& a, const WideLd
                 double acc[NACC];
 #pragma unroll
                 for (int p = 0; p < NACC; ++p) acc[p] = 0.0;
+                ++npass;
+                lap(5);
                 slab_dma(0, 0);                                // (not across the pass boundary: the parked system lies over both buffers)
                 for (int slab = 0; slab < nslab; ++slab) {
                     const int r0 = slab * WRS, cur = slab & 1;
                     const double* s_P = s_slab + cur * WSLAB;                 // local row l = mesh row r0 - 1 + l
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces of the slab have landed
                     __syncthreads();                                          // ... and everybody's; the other buffer is no longer read
+                    lap(0);
                     if (slab + 1 < nslab) slab_dma(slab + 1, cur ^ 1);        // the next slab lands while this one is worked on
                     // ---- four lanes per row i = r0 + q4: u_{i-1}, u_i, u_{i+1} = Phi q (:773), then A(u), R(u) of row i --------------
                     {
@@ -292,6 +463,7 @@ __device__ __forceinline__ void rom_wide_body(const WideRunArgs& a, const WideLd
                             *reinterpret_cast<double2*>(&s_cf[i][2]) = make_double2(up, R);
                         }
                     }
+                    lap(1);
                     if (proj) {
                         __syncthreads();                                      // the slab's coefficients (and u) are in LDS
                         // ---- projection: four steps of 16 rows; lane (k, blk, t): row 16 st + 4 k + blk, columns 24 t + c -------------
@@ -316,120 +488,20 @@ __device__ __forceinline__ void rom_wide_body(const WideRunArgs& a, const WideLd
                             wide_step_mfma<GAL, W>(Y, P, X, acc);
                         }
                     }
+                    lap(2);
                 }
                 __syncthreads();                               // the last slab's rows are no longer read (the system is parked over them)
                 if (!proj) break;                              // that was the lift for U[:, n+1] = Phi q (:779)
                 // ---- park the reduced system (over the dead slabs) ---------------------------------------------------------------
                 wide_park<GAL, W>(acc, S, lane);
                 __syncthreads();
+                lap(3);
                 // ---- solve(Ar, -br) (:767): guarded pivot-free Gauss-Jordan, two row tiles, panels of four columns ---------------
-                // wave w owns the column blocks b = w, w + 4, ... (six of 24); the right-hand side rides with wave 3.
-                // col[s][tile][tt] = entry (row 64 tile + lane, column 4 (w + 4 s) + tt)
-                double col[6][2][4], rhs[2];
-                auto entry = [&](int i, int j) -> double {   // (Ar | br)[i][j]; LSPG: the lower blocks by symmetry
-                    int rr = i, cc = j;
-                    if (!GAL && j < WR && (i % 24) > (j % 24)) { rr = j; cc = i; }
-                    return S[rr * WPS + cc];
-                };
-#pragma unroll
-                for (int tile = 0; tile < 2; ++tile) {
-                    const int row = 64 * tile + lane;
-                    const bool rin = row < WR;
-#pragma unroll
-                    for (int s = 0; s < 6; ++s) {
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt) {
-                            const int j = 4 * (w + 4 * s) + tt;
-                            double v = 0.0;
-                            if (rin) v = (row >= r || j >= r) ? ((row == j) ? 1.0 : 0.0) : entry(row, j);
-                            col[s][tile][tt] = v;
-                        }
-                    }
-                    rhs[tile] = (w == 3 && rin && row < r) ? -entry(row, WR) : 0.0;
-                }
                 const double wtu0 = (lane < r) ? S[lane * WPS + WR + 1] : 0.0;                     // Phi^T u, rows 0 .. 63
                 const double wtu1 = (64 + lane < r) ? S[(64 + lane) * WPS + WR + 1] : 0.0;         // rows 64 .. 95
-                double gmax = 0.0;
-                bool zero_piv = false;
-                __syncthreads();                               // every wave has its columns: S may be overwritten by nobody until the next pass
-#pragma unroll
-                for (int p = 0; p < WNB; ++p) {
-                    const int ow = p & 3, os = p >> 2;         // owner wave and slot of panel p (compile-time after unrolling)
-                    const int tk = (4 * p) / 64;               // row tile of the panel's pivots
-                    if (w == ow) {
-                        // factor the panel in the owner's registers; multipliers for all 96 rows -> s_m[kk][row]
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const int kr = 4 * p + kk, lk = kr & 63;
-                            const double piv = readlane_f64(col[os][tk][kk], lk);
-                            const double rp = rcp(piv);
-                            zero_piv = zero_piv | (piv == 0.0);
-#pragma unroll
-                            for (int tile = 0; tile < 2; ++tile) {
-                                const int row = 64 * tile + lane;
-                                const double m = (row != kr && row < WR) ? col[os][tile][kk] * rp : 0.0;    // rows above the pivot too
-                                gmax = fmax(gmax, (row > kr) ? fabs(m) : 0.0);
-#pragma unroll
-                                for (int jj = kk + 1; jj < 4; ++jj)
-                                    col[os][tile][jj] = __builtin_fma(-m, readlane_f64(col[os][tk][jj], lk), col[os][tile][jj]);
-                                if (row < WR) s_m[kk][row] = m;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    // every wave applies the panel to its later blocks (and wave 3 to the right-hand side)
-                    double m[4][2];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        m[kk][0] = s_m[kk][lane];
-                        m[kk][1] = (lane < WR - 64) ? s_m[kk][64 + lane] : 0.0;
-                    }
-#pragma unroll
-                    for (int s = 0; s < 6; ++s) {
-                        const int b = w + 4 * s;               // this wave's block in slot s
-                        if (b > p) {
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) {
-                                const int lk = (4 * p + kk) & 63;
-                                double pv[4];
-#pragma unroll
-                                for (int tt = 0; tt < 4; ++tt) pv[tt] = readlane_f64(col[s][tk][tt], lk);
-#pragma unroll
-                                for (int tile = 0; tile < 2; ++tile)
-#pragma unroll
-                                    for (int tt = 0; tt < 4; ++tt) col[s][tile][tt] = __builtin_fma(-m[kk][tile], pv[tt], col[s][tile][tt]);
-                            }
-                        }
-                    }
-                    if (w == 3) {
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const int lk = (4 * p + kk) & 63;
-                            const double pv = readlane_f64(rhs[tk], lk);
-                            rhs[0] = __builtin_fma(-m[kk][0], pv, rhs[0]);
-                            rhs[1] = __builtin_fma(-m[kk][1], pv, rhs[1]);
-                        }
-                    }
-                    __syncthreads();                           // s_m is free for the next panel
-                }
-                // what is left is diagonal: x_k = y_k / d_k.  Publish d (the owner of each column) and y (wave 3).
-#pragma unroll
-                for (int s = 0; s < 6; ++s) {
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const int j = 4 * (w + 4 * s) + tt;   // this column's diagonal entry sits in row j
-                        if (lane == (j & 63)) s_diag[j] = col[s][j >> 6][tt];
-                    }
-                }
-                if (w == 3) {
-                    s_y[lane] = rhs[0];
-                    if (lane < WR - 64) s_y[64 + lane] = rhs[1];
-                }
-                {
-                    const unsigned long long anybad = __ballot(zero_piv | !(gmax <= 1.0));
-                    if (lane == 0) s_bad[w] = anybad != 0ull;
-                }
-                __syncthreads();
+                wide_solve<GAL>((lds_double_t*)S, (lds_double_t*)&s_m[0][0], (lds_double_t*)s_diag, (lds_double_t*)s_y,
+                                (lds_int_t*)s_bad, W, lane, r);
+                lap(4);
                 const bool tripped = ((s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0) || a.force_handback;   // workgroup-uniform
                 if (tripped) aborted = true;
                 // ---- q = Phi^T u_k + dq, err = |dq| / |q|  (:770-776) -----------------------------------------------------------
@@ -461,6 +533,10 @@ __device__ __forceinline__ void rom_wide_body(const WideRunArgs& a, const WideLd
             a.flags[smp] = flags;
             a.info[smp] = aborted ? BG_INFO_NEEDS_PIVOTING : info_out;
         }
+        if (kWT && W == 0 && tid == 0 && a.nsteps >= 8) {
+            for (int i = 0; i < 6; ++i) a.iters[(size_t)smp * a.nsteps + i] = (int)(cyc[i] >> 10);
+            a.iters[(size_t)smp * a.nsteps + 6] = npass;
+        }
     }
 }
 
@@ -473,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void rom_wide_kernel(WideRunArgs a)
     __shared__ double s_g[NPADM], s_h[NPADM], s_fdt[NPADM];
     __shared__ __attribute__((aligned(16))) double s_cf[NPADM][4];                // lo, di, up, R per mesh row
     __shared__ __attribute__((aligned(16))) double s_q[WR];
-    __shared__ double s_m[4][WR];                                                 // multipliers of the current panel
+    __shared__ double s_m[8][WR];                                                 // multipliers of the current and the next panel
     __shared__ double s_diag[WR], s_y[WR];
     __shared__ int s_bad[4];
     const WideLdsPtrs L{s_slab, s_u, s_g, s_h, s_fdt, s_cf, s_q, s_m, s_diag, s_y, s_bad};

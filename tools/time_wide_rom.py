@@ -8,6 +8,7 @@ import numpy as np, torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024); ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--r", type=int, default=96); ap.add_argument("--library", action="store_true")
+ap.add_argument("--phases", action="store_true", help="BG_WIDE_TIMING build (BG_LIB_PATH): kilo-clocks per phase and pass")
 a = ap.parse_args()
 from burgers_hip import rom
 g = np.load(os.path.join(REPO, "tests", "golden", "committed_pod_r96.npz"))
@@ -21,5 +22,12 @@ for proj in ("Galerkin", "LSPG"):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); res = run(); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1); its = int(res.iters.sum().item())
+    if a.phases:
+        it = res.iters[:, :7].double().cpu().numpy(); npass = np.median(it[:, 6])
+        names = ["wait slab + barrier", "lift + assembly", "projection (+ coefficient barrier)", "park", "solve", "update / per-step / pass start"]
+        print(f"{proj}: {ms:.1f} ms, passes per sample (median) {npass:.0f}; kilo-clocks per pass: " +
+              ", ".join(f"{nm} {np.median(it[:, i]) * 1.024 / npass:.1f}" for i, nm in enumerate(names)) +
+              f"; total {np.median(it[:, :6].sum(1)) * 1.024 / npass:.1f} k")
+        continue
     print(f"{'library path' if a.library else 'bg_rom_run_wide'} {proj} r={a.r} B={a.batch} steps={a.steps}: {ms:.1f} ms, {its} sample-iterations, "
           f"{its / ms * 1e3:.3g} sample-Newton-steps/s" + (f", handed back {res.redone}" if hasattr(res, 'redone') else ""))
