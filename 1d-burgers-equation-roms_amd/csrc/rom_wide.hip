@@ -219,8 +219,8 @@ __device__ __attribute__((noinline)) void wide_solve(const lds_double_t* S, lds_
     __syncthreads();
     // One barrier per panel: while the other waves apply panel p to their later blocks, the owner of panel p + 1 brings that
     // block up to date first, factors it and publishes its multipliers (look-ahead), then does the rest.
-    auto panels = [&](int p0, int p1, auto tk_c) {          // the pivots of panels [p0, p1) sit in row tile TK
-        constexpr int TK = decltype(tk_c)::value;
+    double mprev[4][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+    auto panels = [&](int p0, int p1, auto tk_c, auto tkprev_c) {   // pivots of panels [p0, p1) in row tile TK, of panel p0 - 1 in TKPREV
 #pragma unroll 1
         for (int p = p0; p < p1; ++p) {
             double m[4][2];
@@ -230,20 +230,29 @@ __device__ __attribute__((noinline)) void wide_solve(const lds_double_t* S, lds_
                 m[kk][1] = (lane < WR - 64) ? s_m[((p & 1) * 4 + kk) * WR + 64 + lane] : 0.0;
             }
             const int nxt = p + 1;
-            if (nxt < WNB && (nxt & 3) == w) {
+            const bool owner_next = nxt < WNB && (nxt & 3) == w;
+            const bool owner_this = p > 0 && (p & 3) == w;       // owned panel p: its other blocks still lack panel p - 1
+            if (owner_next) {
                 with_slot(nxt >> 2, [&](auto sl) {
                     apply(p, sl, tk_c, m);
                     if (nxt < 16) factor(nxt, sl, std::integral_constant<int, 0>{});
                     else factor(nxt, sl, std::integral_constant<int, 1>{});
                 });
+            } else {
+                // the wave that factors the next panel leaves its other blocks for the next round (it is on the critical
+                // path: one block update + one factorisation against six block updates of the others)
+                auto own = [&](auto sl) {                  // this wave's block in slot SL
+                    const int b = w + 4 * decltype(sl)::value;
+                    if (b > p) {
+                        if (owner_this) apply(p - 1, sl, tkprev_c, mprev);
+                        apply(p, sl, tk_c, m);
+                    }
+                };
+                own(std::integral_constant<int, 0>{}); own(std::integral_constant<int, 1>{}); own(std::integral_constant<int, 2>{});
+                own(std::integral_constant<int, 3>{}); own(std::integral_constant<int, 4>{}); own(std::integral_constant<int, 5>{});
             }
-            auto own = [&](auto sl) {                      // this wave's block in slot SL
-                const int b = w + 4 * decltype(sl)::value;
-                if (b > p && b != nxt) apply(p, sl, tk_c, m);
-            };
-            own(std::integral_constant<int, 0>{}); own(std::integral_constant<int, 1>{}); own(std::integral_constant<int, 2>{});
-            own(std::integral_constant<int, 3>{}); own(std::integral_constant<int, 4>{}); own(std::integral_constant<int, 5>{});
             if (w == 3) {
+                constexpr int TK = decltype(tk_c)::value;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int lk = (4 * p + kk) & 63;
@@ -252,11 +261,16 @@ __device__ __attribute__((noinline)) void wide_solve(const lds_double_t* S, lds_
                     rhs[1] = __builtin_fma(-m[kk][1], pv, rhs[1]);
                 }
             }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { mprev[kk][0] = m[kk][0]; mprev[kk][1] = m[kk][1]; }
             if (p + 1 < WNB) __syncthreads();
         }
     };
-    panels(0, 16, std::integral_constant<int, 0>{});
-    panels(16, WNB, std::integral_constant<int, 1>{});
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    panels(0, 16, T0{}, T0{});
+    panels(16, 17, T1{}, T0{});                    // panel 16's deferred predecessor (15) has its pivots in the first row tile
+    panels(17, WNB, T1{}, T1{});
     // what is left is diagonal: x_k = y_k / d_k.  Publish d (the owner of each column) and y (wave 3).
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
