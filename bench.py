@@ -70,7 +70,7 @@ def parse_args(argv=None):
                     help="1-GPU fom run: append short runs of BASELINE configs[2..4] as other_configs.  auto = full for the "
                          "driver's default command line, none once a workload flag is given; small = 96 samples x 12 steps "
                          "(the contract test)")
-    ap.add_argument("--other-steps", type=int, default=2, help="timed passes of each other_configs entry")
+    ap.add_argument("--other-steps", type=int, default=3, help="timed passes of each other_configs entry")
     args = ap.parse_args(argv)
     # the driver's own line (no workload flag given): configs[1] as the headline + one short run of every other config
     args.default_workload = (args.config == "fom" and args.batch is None and args.n is None and args.dt is None
@@ -737,6 +737,11 @@ def _run_rank(args, real_stdout):
     if dist is not None and args.config == "fom":
         gather = allgather_svd_ms(w, res, dist, backend)
 
+    others = None
+    if rank == 0 and args.gpus == 1 and args.config == "fom" and args.other_configs != "none":
+        # before the CPU legs: half a minute of host-only work lets the GPU's clocks fall, and the first config after it
+        # measured 15 % low
+        others = other_config_entries(args, dev, barrier)
     if rank == 0:
         value = total_units * args.steps / elapsed
         metric, workload = w.describe()
@@ -756,10 +761,8 @@ def _run_rank(args, real_stdout):
         if gather is not None:
             line["allgather_svd"] = gather
             line["allgather_svd_ms"] = gather["allgather_svd_ms"]
-        if args.gpus == 1 and args.config == "fom" and args.other_configs != "none":
-            w = res = None
-            torch.cuda.empty_cache()
-            line["other_configs"] = other_config_entries(args, dev, barrier)
+        if others is not None:
+            line["other_configs"] = others
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
