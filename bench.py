@@ -294,8 +294,10 @@ class RomWorkload(Workload):
 
     def roofline(self, units, kernel_s):
         tf = units * self.flops_per_step / kernel_s / 1e12
+        tr = measured_traffic(self.kind, self.args)
         return {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
-                "traffic": None, "kernel": self.kernel_name, "pass_ms_avg": kernel_s * 1e3,
+                "traffic": tr["bytes"] if tr else None, **({"traffic_source": tr["source"]} if tr else {}),
+                "kernel": self.kernel_name, "pass_ms_avg": kernel_s * 1e3,
                 "algorithmic_flops_per_step": self.flops_per_step,
                 "measured_ceiling_of_the_instruction_used": {"instruction": "v_mfma_f64_4x4x4_4b_f64",
                                                              "TFLOP/s": FP64_MFMA_4X4X4_MEASURED_TF,
@@ -582,6 +584,20 @@ def cpu_leg(w, res, timed):
 def measured_traffic(kind, args):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes,
     FETCH doubled per MI355X_MICROARCH section HBM) -- only when it was collected on THIS configuration."""
+    if kind != "fom":                                      # ROM configs: profiles/rom_pmc_summary.json, full bench sizes only
+        default = parse_args(["--config", kind])
+        if (args.batch, args.n, args.time_steps, args.dt) != (default.batch, default.n, default.time_steps, default.dt):
+            return None
+        try:
+            with open(os.path.join(REPO, "profiles", "rom_pmc_summary.json")) as f:
+                d = json.load(f)
+            rec = d["configs"][kind]
+        except Exception:
+            return None
+        return {"bytes": rec["hbm_bytes_per_launch"],
+                "source": "profiles/rom_pmc_summary.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same "
+                          "configuration, round %s: %.3g B fetched + %.3g B written by %s; not re-measured in this run)"
+                          % (d.get("round", "?"), rec["fetch_bytes_per_launch"], rec["write_bytes_per_launch"], rec["kernel"][:40])}
     path = os.path.join(REPO, "profiles", "fom_pmc_summary.json")
     try:
         with open(path) as f:

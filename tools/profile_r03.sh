@@ -39,5 +39,35 @@ import json,sys
 d=json.loads(sys.stdin.read()); print(json.dumps({k: d[k] for k in ('value','ms_per_step','steps') } | {'units_per_pass': d['config']['units_per_pass'], 'workload': d['config']['workload']}))" > $O/r03_${cfg}_bench_under_sq_pass.json || true
   echo "$cfg done"; cat $O/r03_${cfg}_pmc.json | head -60
 done
+# HBM traffic of the hot kernel at the FULL bench configuration (what bench.py reports as roofline.traffic of these configs)
+if [ -z "$NO_FULL_TRAFFIC" ]; then
+for cfg in ${CONFIGS:-pod_galerkin pod_lspg quadratic ann}; do
+  case $cfg in
+    pod_*) key="rom_fused_kernel";;
+    quadratic) key="quad_fused_kernel";;
+    ann) key="rom_ann_fused_kernel";;
+  esac
+  mkdir -p $W/full_$cfg
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $W/full_$cfg/fetch -- python $R/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline > $W/full_$cfg/fetch.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $W/full_$cfg/write -- python $R/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline > $W/full_$cfg/write.log 2>&1
+  python3 $R/tools/summarize_pmc.py $W/full_$cfg $key > $O/r03_${cfg}_full_traffic.json
+  echo "$cfg full-size traffic done"
+done
+python3 - $O <<'PY'
+import glob, json, os, sys
+o = sys.argv[1]
+out = {"round": "r03", "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --config NAME --steps 1 --warmup 0` (the full "
+       "bench configuration); KiB -> bytes; FETCH_SIZE x2 (gfx950, MI355X_MICROARCH section HBM); the launch with the largest grid", "configs": {}}
+for f in sorted(glob.glob(os.path.join(o, "r03_*_full_traffic.json"))):
+    cfg = os.path.basename(f)[4:-len("_full_traffic.json")]
+    recs = [r for r in json.load(open(f)) if "hbm_bytes_per_launch" in r]
+    if recs:
+        r = max(recs, key=lambda r: r["hbm_bytes_per_launch"])
+        out["configs"][cfg] = {"kernel": r["kernel"], "hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "fetch_bytes_per_launch": r["hbm_fetch_bytes_per_launch"],
+                               "write_bytes_per_launch": r["hbm_write_bytes_per_launch"]}
+json.dump(out, open(os.path.join(o, "rom_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+fi
 rm -rf $W
 ls -la $O
