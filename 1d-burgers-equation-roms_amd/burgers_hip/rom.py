@@ -486,12 +486,17 @@ class QuadFusedPlan:
         self.PhiT[:n, :N] = self.Phi.t()
         Pp = torch.zeros((4 * NG, 40), **f64)
         Pp[:N, :n] = self.Phi
-        # (rg, blk, i, c) -> [rg][c][4 i + blk]
-        self.Phif = Pp.reshape(NG, 4, 4, 10).permute(0, 3, 2, 1).contiguous()
+        # accumulator seeds of the tangent tiles: (rg, blk, c, i) -> [rg][c][4 i + blk]
+        self.Phif = Pp.reshape(NG, 4, 10, 4).permute(0, 2, 3, 1).contiguous()
         H3p = torch.zeros((4 * NG, 40, 40), **f64)
         H3p[:N, :n, :n] = quad_tangent_tensor(self.Phi, self.H)
-        # row 4 rg + blk, column 10 i + c, k index 8 kc2 + 4 e + k:  (rg, blk, i, c, kc2, e, k) -> [rg][c][kc2][k][blk][i][e]
-        self.H3f = H3p.reshape(NG, 4, 4, 10, 5, 2, 4).permute(0, 3, 4, 6, 1, 2, 5).contiguous()
+        # H3 of a mesh row is symmetric: only its upper 4 x 4 blocks (a <= b, row-major) travel.  Block (a, b), lane 16 k + 4 blk + i
+        # = H3[4 rg + blk][4 a + i][4 b + k]; two blocks per 16-byte slot: [rg][slot (28)][lane][2] (block 55 = zero padding)
+        Hb = H3p.reshape(NG, 4, 10, 4, 10, 4).permute(0, 2, 4, 5, 1, 3)           # (rg, a, b, k, blk, i)
+        A_, B_ = np.triu_indices(10)
+        Hu = Hb[:, torch.as_tensor(A_, device=device), torch.as_tensor(B_, device=device)].reshape(NG, 55, 64)
+        Hu = torch.cat([Hu, torch.zeros((NG, 1, 64), **f64)], 1)
+        self.H3f = Hu.reshape(NG, 28, 2, 64).permute(0, 1, 3, 2).contiguous()
         assert self.H3f.numel() == L.bg_quad_rom_h3f_elems(N) and self.Phif.numel() == L.bg_quad_rom_phif_elems(N)
 
 

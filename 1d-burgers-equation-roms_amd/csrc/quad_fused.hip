@@ -44,12 +44,17 @@ constexpr int QTR = QRS + 8;           // tangent rows held per slab: [r0 - 4, r
 constexpr int QTS = 42;                // doubles per tangent row in LDS (16-byte aligned rows, banks spread)
 constexpr int QTJ = QTR * QTS + 4;     // doubles per sample in s_T
 constexpr int QSYS = QN + 1;           // row length of the reduced system parked in LDS: Ar | br
-#ifndef BG_QUAD_CHUNK
-#define BG_QUAD_CHUNK 5
+constexpr int QPAIRS = QNB * (QNB + 1) / 2;   // 4 x 4 blocks (a <= b) of the symmetric tangent tensor of a mesh row: 55
+constexpr int QP2 = (QPAIRS + 1) / 2;         // 16-byte load slots per lane and row group: 28
+constexpr int QRING = QTR / 4;                // row groups the LDS ring of tangent rows holds: 18
+constexpr int qpair(int a, int b) { return a * QNB - a * (a - 1) / 2 + (b - a); }      // a <= b, row-major upper triangle
+constexpr int qrow(int p) { int a = 0; while (a + 1 < QNB && qpair(a + 1, a + 1) <= p) ++a; return a; }
+constexpr int qcol(int p) { return qrow(p) + (p - qpair(qrow(p), qrow(p))); }
+#ifndef BG_QUAD_WINDOW
+#define BG_QUAD_WINDOW 14
 #endif
-constexpr int QCH = BG_QUAD_CHUNK;     // tangent tiles whose operands are in flight per wave (divides 45): 5 x 80 bytes per lane
-                                       // (measured: 3 and 5 alike, 9 spills and loses a third)
-static_assert(45 % QCH == 0, "a wave's 45 tiles per slab split into whole chunks");
+constexpr int QW = BG_QUAD_WINDOW;            // 16-byte slots of the tangent stream in flight per wave (divides 28)
+static_assert(QP2 % QW == 0, "the ring of slots runs across row groups with static indices");
 #ifdef BG_QUAD_TIMING                   // diagnostic builds (tools/time_quad_fused.py): shader clocks per phase instead of the counts
 constexpr bool kQT = true;
 #else
@@ -59,8 +64,8 @@ constexpr bool kQT = false;
 struct QuadRunArgs {
     const double* x;        // [N]
     const double* PhiT;     // [40][NPAD]   Phi^T, zero padded
-    const double* Phif;     // [NG][10][16] Phi[4 rg + blk][10 i + c] at (4 i + blk): accumulator seed of a tangent tile
-    const double* H3f;      // [NG][10][5][64][2]  tangent tensor, A-operand order (see bg_quad_rom_run)
+    const double* Phif;     // [NG][10][16] Phi[4 rg + blk][4 c + i] at [rg][c][4 i + blk]: accumulator seed of tangent tile c
+    const double* H3f;      // [NG][28][64][2]  upper 4 x 4 blocks of the symmetric tangent tensor, A-operand order (see bg_quad_rom_run)
     const double* u0;       // [B][N]
     const double* mu1;      // [B]
     const double* mu2;      // [B]
@@ -101,6 +106,7 @@ __global__ __launch_bounds__(256, 1) void quad_fused_kernel(QuadRunArgs a)
     // lane roles: projection operand (k, blk, t), tangent result (i, blk, j)
     const int pk = lane >> 4, pblk = (lane >> 2) & 3, pt = lane & 3;
 
+    for (int e = tid; e < QG * QTJ; e += 256) s_T[e] = 0.0;        // ring slots are read before their first write (row -1 of slab 0): keep them finite
     const int ngroups = (a.B + QG - 1) / QG;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int smp = grp * QG + w;
@@ -145,20 +151,93 @@ __global__ __launch_bounds__(256, 1) void quad_fused_kernel(QuadRunArgs a)
             }
         };
         int npass = 0;
-        // A operands (H3, fragment-major) and accumulator seeds (Phi) of the QCH tangent tiles in flight (see the tile loop)
-        double2 av[QCH][QKC / 2];
-        double tphi[QCH];
-        auto load_tile = [&](int slab_i, int m, double2 (&dst)[QKC / 2], double& seed) {
-            const int tile = w + 4 * m;
-            const int gl = tile / QNB, c = tile - gl * QNB;
-            int rg = slab_i * (QRS / 4) - 1 + gl;
-            rg = rg < 0 ? 0 : (rg >= a.NG ? a.NG - 1 : rg);                   // clamped: the result of such a tile is discarded
-            const size_t tb = (size_t)rg * QNB + c;
-            const double2* ap = reinterpret_cast<const double2*>(a.H3f) + tb * (QKC / 2) * 64 + lane;
-#pragma unroll
-            for (int k2 = 0; k2 < QKC / 2; ++k2) dst[k2] = ap[k2 * 64];
-            seed = a.Phif[tb * 16 + (lane >> 2)];
+        // T rows of a row group (4 mesh rows) for the four samples.  H3 of a mesh row is symmetric: only its 55 upper 4 x 4 blocks
+        // (a <= b) are stored and streamed -- 3.7 MB instead of 6.5 MB per pass through the CU's vector-memory path, which bounded
+        // this phase (first version: every (tile, k chunk) operand loaded, 48 B/clk/CU).  Block (a, b) feeds tile a as it stands
+        // (k chunk b) and, if a < b, tile b transposed (k chunk a): the transposed operand wants the value of lane (i, blk, k) in
+        // lane (k, blk, i), two ds_bpermute.  The blocks are consumed in storage order, two per 16-byte slot, against the ten
+        // tile accumulators (two chains each: even / odd k chunk), so a slot is dead after at most four matrix instructions and
+        // the ring of QW slots in flight runs seamlessly from one row group into the wave's next one.
+        double2 hs[QW];
+        double sd[QNB], sdn[QNB];                                             // accumulator seeds (Phi) of this group / the next one
+        auto slot_ptr = [&](int g) {
+            const int rg = g < 0 ? 0 : (g >= a.NG ? a.NG - 1 : g);            // clamped: the result of such a group is discarded
+            return reinterpret_cast<const double2*>(a.H3f) + (size_t)rg * QP2 * 64 + lane;
         };
+        auto load_seeds = [&](int g, double (&dst)[QNB]) {
+            const int rg = g < 0 ? 0 : (g >= a.NG ? a.NG - 1 : g);
+            const double* pp = a.Phif + (size_t)rg * QNB * 16 + (lane >> 2);
+#pragma unroll
+            for (int c = 0; c < QNB; ++c) dst[c] = pp[c * 16];
+        };
+        auto start_stream = [&](int g) {                                      // the first QW slots and the seeds of group g
+            const double2* hp = slot_ptr(g);
+#pragma unroll
+            for (int p2 = 0; p2 < QW; ++p2) hs[p2] = hp[p2 * 64];
+            load_seeds(g, sd);
+        };
+        auto tangent_group = [&](int g, int gnext, const double (&bq)[QKC]) {
+            const int ti = lane >> 4, tblk = (lane >> 2) & 3, tj = lane & 3;
+            const bool inside = g >= 0 && g < a.NG;
+            const int trsrc = (16 * (lane & 3) + 4 * tblk + ti) << 2;         // byte index of the lane whose value this lane takes in a transpose
+            const double2* hp = slot_ptr(g);
+            const double2* hn = slot_ptr(gnext);
+            load_seeds(gnext, sdn);
+            double d[QNB][2];
+            double pq = 0.0;                            // (Phi q)[row 4 g + blk][sample j]: the seeds ARE Phi, and bq[c] = q_j[4 c + i]
+#pragma unroll
+            for (int c = 0; c < QNB; ++c) { d[c][0] = sd[c]; d[c][1] = 0.0; pq = __builtin_fma(sd[c], bq[c], pq); }
+            pq += from_lane_rot(pq, (lane ^ 16) << 2);                       // sum over i = lane bits 4, 5
+            pq += from_lane_rot(pq, (lane ^ 32) << 2);
+            if (ti == 0 && g >= 0 && 4 * g + tblk < 512) s_u[tj][2 + 4 * g + tblk] = inside ? pq : 0.0;      // seeds u = 1/2 (Phi q + T q) of the row's slab
+            // transposes run one slot ahead of the products that consume them (a ds_bpermute result is ~100 clocks away:
+            // computed in the slot's own turn each slot stalled for it, 2 k clocks per group)
+            auto transposes = [&](int p2, double (&tr)[2]) {
+                if (p2 < QP2) {
+                    const double2 v2 = hs[p2 % QW];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int p = 2 * p2 + e;
+                        if (p < QPAIRS && qrow(p) != qcol(p)) tr[e] = from_lane_rot(e ? v2.y : v2.x, trsrc);
+                    }
+                }
+            };
+            double trn[2] = {0.0, 0.0};
+            transposes(0, trn);
+#pragma unroll
+            for (int p2 = 0; p2 < QP2; ++p2) {
+                const double2 v2 = hs[p2 % QW];
+                const double tr[2] = {trn[0], trn[1]};
+                transposes(p2 + 1, trn);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int p = 2 * p2 + e;
+                    if (p < QPAIRS) {
+                        const int ra = qrow(p), cb = qcol(p);
+                        d[ra][cb & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(e ? v2.y : v2.x, bq[cb], d[ra][cb & 1], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int p = 2 * p2 + e;
+                    if (p < QPAIRS && qrow(p) != qcol(p)) {
+                        const int ra = qrow(p), cb = qcol(p);
+                        d[cb][ra & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(tr[e], bq[ra], d[cb][ra & 1], 0, 0, 0);
+                    }
+                }
+                // the slot is dead: refill it with slot p2 + QW of this group, or of the wave's next one (no branch: a join would drain the ring)
+                hs[p2 % QW] = (p2 + QW < QP2) ? hp[(p2 + QW) * 64] : hn[(p2 + QW - QP2) * 64];
+            }
+            // result lane 16 i + 4 blk + j: T[sample j][row 4 g + blk][column 4 c + i]; groups outside the mesh are zero rows
+            double* trow = s_T + tj * QTJ + (4 * ((g + 1) % QRING) + tblk) * QTS + ti;
+#pragma unroll
+            for (int c = 0; c < QNB; ++c) {
+                trow[4 * c] = inside ? d[c][0] + d[c][1] : 0.0;
+                sd[c] = sdn[c];
+            }
+        };
+        // mesh row i (>= -4) -> row of the ring of tangent rows in LDS (group g sits in slot (g + 1) mod 18)
+        auto ring_row = [](int i) { return 4 * (((i + 4) >> 2) % QRING) + ((i + 4) & 3); };
 
         for (int step = 0; step < a.nsteps; ++step) {
             // ---- g = M u^n + dt F (`M @ U[:, m] + At*F`, :1144), q = Phi^T u^n (:1129); wave-local ------------------
@@ -212,31 +291,10 @@ __global__ __launch_bounds__(256, 1) void quad_fused_kernel(QuadRunArgs a)
             lap(7);
             while (true) {
                 ++npass;
-                // ---- pass start: publish q and the activity flag, seed u with Phi q ----------------------------------
+                // ---- pass start: publish q and the activity flag (Phi q, the seed of the decode, comes out of the tangent stream) ----
                 if (lane < QN) s_q[w][lane] = q;
                 if (lane == 0) s_act[w] = act ? 1 : 0;
-                {
-                    double p[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                    for (int c0 = 0; c0 < QN; c0 += 8) {        // eight columns (64 loads) in flight; PhiT rows beyond n are zero
-                        double f[8][8];
-#pragma unroll
-                        for (int cc = 0; cc < 8; ++cc) {
-                            const double* pc = a.PhiT + (size_t)(c0 + cc) * NPAD + lane;
-#pragma unroll
-                            for (int m = 0; m < 8; ++m) f[cc][m] = (64 * m < NPAD) ? pc[64 * m] : 0.0;
-                        }
-#pragma unroll
-                        for (int cc = 0; cc < 8; ++cc) {
-                            const double qc = readlane_f64(q, c0 + cc);
-#pragma unroll
-                            for (int m = 0; m < 8; ++m) p[m] = __builtin_fma(f[cc][m], qc, p[m]);
-                        }
-                    }
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) s_u[w][2 + lane + 64 * m] = p[m];
-                }
-#pragma unroll
-                for (int i = 0; i < QCH; ++i) load_tile(0, i, av[i], tphi[i]);      // the first tangent tiles of the pass
+                start_stream(w == 0 ? 0 : 1 + 4 * w);
                 lap(0);
                 __syncthreads();
                 lap(5);
@@ -251,46 +309,23 @@ __global__ __launch_bounds__(256, 1) void quad_fused_kernel(QuadRunArgs a)
 
                 for (int slab = 0; slab < nslab; ++slab) {
                     const int r0 = slab * QRS;
-                    // ---- tangent tiles of rows [r0 - 4, r0 + 68) for the four samples: 180 tiles, 45 per wave ------------
-                    // The A operands of the next QCH tiles are always in flight: the loads of tile i of the NEXT chunk are
-                    // issued right behind the matrix instructions of tile i of this one, into the same registers (first
-                    // version: load, wait, multiply per tile -- 290 us per pass, all of it memory latency).  The chunk after a
-                    // slab's last one belongs to the next slab, so it streams in under the decode and the projection.
+                    // ---- tangent rows of the row groups 16 slab + 1 .. 16 slab + 16 for the four samples, four groups per wave ----------
+                    // (the LDS ring still holds groups 16 slab - 1 and 16 slab from the previous slab: rows r0 - 1 .. r0 + 64 are
+                    // what the decode and the projection of rows r0 .. r0 + 63 read)
                     {
-                        const int ti = lane >> 4, tblk = (lane >> 2) & 3, tj = lane & 3;
+                        const int g0 = 16 * slab + 1 + 4 * w;
+                        const int first = (w == 0) ? 0 : 1 + 4 * w;                        // this wave's first group of a pass
+                        if (slab == 0 && w == 0) tangent_group(0, g0, bq);
 #pragma unroll 1
-                        for (int ch = 0; ch < 45 / QCH; ++ch) {
-                            const bool wrap = ch + 1 == 45 / QCH;
-                            // no branch around the loads (a wave-uniform `if` puts a vmcnt(0) at its join and the ring drains at
-                            // every tile: 550 clocks per tile instead of 10 matrix instructions); the chunk after the last one
-                            // of a pass re-reads the pass's first tiles and is dropped
-                            const int nslab_i = wrap ? (slab + 1 < nslab ? slab + 1 : 0) : slab;
-                            const int nch = wrap ? 0 : ch + 1;
-#pragma unroll
-                            for (int i = 0; i < QCH; ++i) {
-                                const int tile = w + 4 * (ch * QCH + i);
-                                const int gl = tile / QNB, c = tile - gl * QNB;
-                                const int rg = r0 / 4 - 1 + gl;
-                                // three independent accumulation chains per tile: a dependent v_mfma_f64_4x4x4 waits ~40 clocks
-                                // for its predecessor (one chain of ten: 426 clocks per tile against 165 of issue)
-                                double d3[3] = {tphi[i], 0.0, 0.0};
-#pragma unroll
-                                for (int kc = 0; kc < QKC; ++kc)
-                                    d3[kc % 3] = __builtin_amdgcn_mfma_f64_4x4x4f64((kc & 1) ? av[i][kc / 2].y : av[i][kc / 2].x, bq[kc],
-                                                                                   d3[kc % 3], 0, 0, 0);
-                                const double d = (d3[0] + d3[1]) + d3[2];
-                                // result lane 16 i + 4 blk + j: T[sample j][row 4 rg + blk][column 10 i + c]; groups outside the mesh are zero rows
-                                s_T[tj * QTJ + (4 * gl + tblk) * QTS + 10 * ti + c] = (rg >= 0 && rg < a.NG) ? d : 0.0;
-                                load_tile(nslab_i, nch * QCH + i, av[i], tphi[i]);
-                            }
-                        }
+                        for (int m = 0; m < 4; ++m)
+                            tangent_group(g0 + m, m < 3 ? g0 + m + 1 : (slab + 1 < nslab ? g0 + 16 : first), bq);
                     }
                     lap(1);
                     __syncthreads();
                     lap(2);
                     // ---- decode of this wave's sample, rows [r0, r0 + 64]:  u = 1/2 (Phi q + T q)  (:1116-1118) -------------
                     {
-                        const double* trow = Tw + (4 + lane) * QTS;
+                        const double* trow = Tw + ring_row(r0 + lane) * QTS;
                         double s = 0.0;
 #pragma unroll
                         for (int c4 = 0; c4 < QN / 4; ++c4) {
@@ -307,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void quad_fused_kernel(QuadRunArgs a)
                         s_u[w][2 + i] = (i < N) ? 0.5 * (s_u[w][2 + i] + s) : 0.0;
                         // the row just beyond the slab (its own slab has not come yet: Phi q stays in s_u)
                         const int inx = r0 + QRS;
-                        double v = (lane < QN) ? Tw[(4 + QRS) * QTS + lane] * q : 0.0;
+                        double v = (lane < QN) ? Tw[ring_row(r0 + QRS) * QTS + lane] * q : 0.0;
                         v = wave_sum(v);
                         if (lane == 0) s_unext[w] = (inx < N) ? 0.5 * (s_u[w][2 + inx] + v) : 0.0;
                     }
@@ -336,13 +371,15 @@ __global__ __launch_bounds__(256, 1) void quad_fused_kernel(QuadRunArgs a)
                             const double2 c01 = *reinterpret_cast<const double2*>(&s_coef[w][rl][0]);
                             const double2 c23 = *reinterpret_cast<const double2*>(&s_coef[w][rl][2]);
                             const double lo = c01.x, di = c01.y, up = c23.x, R = c23.y;
-                            const double* tr = Tw + (4 + rl) * QTS + 10 * pt;
+                            const double* trb = Tw + ring_row(r0 + rl - 1) * QTS + 10 * pt;
+                            const double* trm = Tw + ring_row(r0 + rl) * QTS + 10 * pt;
+                            const double* tra = Tw + ring_row(r0 + rl + 1) * QTS + 10 * pt;
                             double Tm[QNB], Y[QNB];
 #pragma unroll
                             for (int c2 = 0; c2 < QNB / 2; ++c2) {
-                                const double2 tb = *reinterpret_cast<const double2*>(tr - QTS + 2 * c2);
-                                const double2 tm = *reinterpret_cast<const double2*>(tr + 2 * c2);
-                                const double2 ta = *reinterpret_cast<const double2*>(tr + QTS + 2 * c2);
+                                const double2 tb = *reinterpret_cast<const double2*>(trb + 2 * c2);
+                                const double2 tm = *reinterpret_cast<const double2*>(trm + 2 * c2);
+                                const double2 ta = *reinterpret_cast<const double2*>(tra + 2 * c2);
                                 Tm[2 * c2] = tm.x; Tm[2 * c2 + 1] = tm.y;
                                 Y[2 * c2] = __builtin_fma(up, ta.x, __builtin_fma(di, tm.x, lo * tb.x));
                                 Y[2 * c2 + 1] = __builtin_fma(up, ta.y, __builtin_fma(di, tm.y, lo * tb.y));
@@ -491,7 +528,7 @@ extern "C" {
 int bg_quad_rom_max_n(void) { return QN; }
 
 // Element counts of the two operand copies bg_quad_rom_run reads (the caller builds them once per basis).
-long long bg_quad_rom_h3f_elems(int N) { return N < 2 ? 0 : (long long)((N + 3) / 4) * QNB * (QKC / 2) * 64 * 2; }
+long long bg_quad_rom_h3f_elems(int N) { return N < 2 ? 0 : (long long)((N + 3) / 4) * QP2 * 64 * 2; }
 long long bg_quad_rom_phif_elems(int N) { return N < 2 ? 0 : (long long)((N + 3) / 4) * QNB * 16; }
 
 int bg_quad_rom_run(int N, int B, int n, int nsteps, int projection, const double* x, const double* PhiT, const double* Phif,

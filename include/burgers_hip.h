@@ -309,9 +309,11 @@ int bg_mlp_act_jvp(int B, int n1, int h, float *z, const float *bias, int act, f
  *   the same rows, assembly, projection and the n x n solve per wave (csrc/quad_fused.hip).  No SUPG term (:1142).
  *   N <= 512, n <= bg_quad_rom_max_n() (40).  Operand copies, built once per basis by the caller (zero padded):
  *     PhiT [40][NPAD]               Phi^T, NPAD = N rounded up to 64
- *     Phif [NG][10][16]             Phi[4 rg + blk][10 i + c] at [rg][c][4 i + blk], NG = ceil(N / 4)
- *     H3f  [NG][10][5][64][2]       H3[4 rg + blk][10 i + c][8 kc2 + 4 e + k] at [rg][c][kc2][16 k + 4 blk + i][e],
- *                                   H3[i][a][c] = H[i][pair(a, c)] (1 + delta_ac)   (the A operand of the matrix instruction)
+ *     Phif [NG][10][16]             Phi[4 rg + blk][4 c + i] at [rg][c][4 i + blk], NG = ceil(N / 4)
+ *     H3f  [NG][28][64][2]          H3[i][a][c] = H[i][pair(a, c)] (1 + delta_ac) is symmetric in (a, c): only its upper 4 x 4
+ *                                   blocks (A <= B, row-major, 55 per mesh-row group) are stored, two per 16-byte slot:
+ *                                   block p = 2 slot + e of row group rg holds, at lane 16 k + 4 blk + i,
+ *                                   H3[4 rg + blk][4 A + i][4 B + k]   (the A operand of the matrix instruction; block 55 = 0)
  *     sizes: bg_quad_rom_phif_elems(N), bg_quad_rom_h3f_elems(N) doubles.
  *   Outputs as bg_rom_run: hist [B][nsteps+1][N], iters [B][nsteps] (Newton iterations per step), flags [B]
  *   (BG_FLAG_HIT_CAP = "Newton did not converge" :1171, BG_FLAG_NONFINITE), info [B]: 0, or k + 1 when the reduced
