@@ -48,7 +48,7 @@ FOM_ALG_FLOP_PER_ROW = 60.0
 # solver (Wang partition + PCR) costs more flops than Thomas, which is why executed > algorithmic.
 FOM_EXEC_FLOP_PER_LANE_ITER = {16: 1033}
 
-CONFIGS = ("fom", "pod_galerkin", "pod_lspg", "quadratic", "ann", "decoder_bf16")
+CONFIGS = ("fom", "pod_galerkin", "pod_lspg", "quadratic", "ann", "decoder_bf16", "pod_r96_galerkin", "pod_r96_lspg")
 
 
 def parse_args(argv=None):
@@ -88,7 +88,7 @@ def parse_args(argv=None):
         args.dt = 0.05 if rom else 0.025
     if args.batch is None:
         args.batch = {"fom": 1024, "pod_galerkin": 4096, "pod_lspg": 4096, "quadratic": 1024, "ann": 2048,
-                      "decoder_bf16": 2048}[args.config]
+                      "decoder_bf16": 2048, "pod_r96_galerkin": 1024, "pod_r96_lspg": 1024}[args.config]
     return args
 
 
@@ -311,9 +311,18 @@ class PodWorkload(RomWorkload):
         super().__init__(*a)
         import torch
         self.kind = self.args.config
-        self.proj = "Galerkin" if self.kind == "pod_galerkin" else "LSPG"
-        self.r = 40
-        (self.Phi,) = self.build_training_bases(n_pod=self.r)
+        self.proj = "Galerkin" if self.kind.endswith("galerkin") else "LSPG"
+        self.wide = self.kind.startswith("pod_r96")
+        if self.wide:
+            # beyond BASELINE's configs: the thesis' tol 1e-04 basis, POD/modes/U_modes_tol_1e-04.npy (512 x 96),
+            # the committed reference artefact itself (data fixture tests/golden/committed_pod_r96.npz)
+            self.r = 96
+            self.Phi = torch.as_tensor(golden("committed_pod_r96.npz")["Phi"], device=self.dev).contiguous()
+            self.kernel_name = ("rom_wide_kernel (bg_rom_run_wide: one launch per pass, the whole time loop of a sample per workgroup; "
+                                "basis streamed through LDS)")
+        else:
+            self.r = 40
+            (self.Phi,) = self.build_training_bases(n_pod=self.r)
         N, r = self.args.n, self.r
         self.flops_per_step = 2 * N * r * r + 11 * N * r + (2 * r ** 3) / 3
         self.u0 = torch.ones((self.args.batch, N), dtype=torch.float64, device=self.dev)
@@ -327,9 +336,10 @@ class PodWorkload(RomWorkload):
 
     def describe(self):
         a = self.args
+        tag = "beyond BASELINE (thesis basis U_modes_tol_1e-04)" if self.wide else "configs[2]"
         return ("batched Newton-steps/sec over mu-sweep (sample-Newton-steps/s, POD-%s ROM r=%d)" % (self.proj, self.r),
-                "configs[2]: POD-%s ROM r=%d, %d-sample batch/GPU, N=%d, fp64, %d steps, dt=%g, V^T J V on fp64 MFMA"
-                % (self.proj, self.r, a.batch, a.n, a.time_steps, a.dt))
+                "%s: POD-%s ROM r=%d, %d-sample batch/GPU, N=%d, fp64, %d steps, dt=%g, V^T J V on fp64 MFMA"
+                % (tag, self.proj, self.r, a.batch, a.n, a.time_steps, a.dt))
 
 
 class QuadWorkload(RomWorkload):
@@ -458,7 +468,7 @@ class DecoderWorkload(Workload):
 
 
 WORKLOADS = {"fom": FomWorkload, "pod_galerkin": PodWorkload, "pod_lspg": PodWorkload, "quadratic": QuadWorkload,
-             "ann": AnnWorkload, "decoder_bf16": DecoderWorkload}
+             "ann": AnnWorkload, "decoder_bf16": DecoderWorkload, "pod_r96_galerkin": PodWorkload, "pod_r96_lspg": PodWorkload}
 
 
 def cpu_model():
@@ -528,7 +538,7 @@ def cpu_leg(w, res, timed):
                                    f"(oracle/burgers_ref_c.c), {t:.1f} s"})
         cpu = dict(legs[-1])
         cpu["legs"] = legs
-    elif w.kind in ("pod_galerkin", "pod_lspg", "quadratic", "ann"):
+    elif w.kind in ("pod_galerkin", "pod_lspg", "quadratic", "ann", "pod_r96_galerkin", "pod_r96_lspg"):
         steps = min(a.time_steps, 10)
         if w.kind == "quadratic":
             Phi, H = w.Phi.cpu().numpy(), w.H.cpu().numpy()
@@ -584,6 +594,8 @@ def cpu_leg(w, res, timed):
 def measured_traffic(kind, args):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes,
     FETCH doubled per MI355X_MICROARCH section HBM) -- only when it was collected on THIS configuration."""
+    if kind.startswith("pod_r96"):
+        return None
     if kind != "fom":                                      # ROM configs: profiles/rom_pmc_summary.json, full bench sizes only
         default = parse_args(["--config", kind])
         if (args.batch, args.n, args.time_steps, args.dt) != (default.batch, default.n, default.time_steps, default.dt):

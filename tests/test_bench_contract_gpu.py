@@ -60,12 +60,13 @@ def test_bench_default_line_carries_the_other_configs(hip):
     d = _run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "64",
               "--time-steps", "20", "--no-cpu-baseline", "--other-configs", "small", "--other-steps", "1"])
     oc = d["other_configs"]
-    assert [e["config"]["name"] for e in oc] == ["pod_galerkin", "pod_lspg", "quadratic", "ann", "decoder_bf16"]
+    assert [e["config"]["name"] for e in oc] == ["pod_galerkin", "pod_lspg", "quadratic", "ann", "decoder_bf16", "pod_r96_galerkin",
+                                                   "pod_r96_lspg"]
     for e in oc:
         assert "error" not in e, e
         assert e["value"] > 0 and e["ms_per_step"] > 0 and e["steps"] == 1 and 0.0 < e["roofline"]["frac"] <= 1.0
         assert e["rel_l2_vs_cpu_ref"] < e["parity_tolerance"] and e["nonfinite_samples"] == 0
-        if e["config"]["name"] in ("pod_galerkin", "pod_lspg", "quadratic"):
+        if e["config"]["name"] in ("pod_galerkin", "pod_lspg", "quadratic", "pod_r96_galerkin", "pod_r96_lspg"):
             assert e["iters_match_cpu_ref"] is True
 
 
