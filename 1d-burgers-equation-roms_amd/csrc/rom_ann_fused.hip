@@ -167,6 +167,10 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         tid = v; lane = v & 63; t = lane & 3; owner = 16 * w + (lane >> 2); rowbase = owner * S;
     };
 
+#ifdef BG_ANN_LDS_PAD                              // timing builds only: extra LDS, so that one workgroup fills a CU
+    __shared__ volatile int s_pad[BG_ANN_LDS_PAD / 4];
+    if (a.B < 0) s_pad[threadIdx.x] = 1;
+#endif
     if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;
     for (int e = tid; e < (NPAD + 2) * RW; e += 256) (&s_W[0][0])[e] = 0.0;
     if (tid < RW) s_q[tid] = 0.0;
