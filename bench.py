@@ -594,8 +594,6 @@ def cpu_leg(w, res, timed):
 def measured_traffic(kind, args):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes,
     FETCH doubled per MI355X_MICROARCH section HBM) -- only when it was collected on THIS configuration."""
-    if kind.startswith("pod_r96"):
-        return None
     if kind != "fom":                                      # ROM configs: profiles/rom_pmc_summary.json, full bench sizes only
         default = parse_args(["--config", kind])
         if (args.batch, args.n, args.time_steps, args.dt) != (default.batch, default.n, default.time_steps, default.dt):
