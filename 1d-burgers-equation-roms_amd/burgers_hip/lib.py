@@ -117,6 +117,12 @@ _SIGNATURES = {
                                       ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
     "bg_decode_modes_bf16": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_void_p, c_double_p, ctypes.c_void_p]),
+    # win / wout / acts (int[]), W / bias (void*[]) and alphas (float[]) are HOST arrays built by the caller
+    "bg_decode_mlp_bf16": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                          c_double_p, c_double_p, c_double_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                          ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
+                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
+                                          ctypes.POINTER(ctypes.c_float), c_double_p, ctypes.c_void_p]),
     "bg_ann_rom_limits": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)] * 4),
     # widths / acts (int[]), wt / bias (void*[]) and alphas (float[]) are HOST arrays built by the caller
     "bg_ann_rom_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -436,6 +436,7 @@ class DecoderWorkload(Workload):
         self.Nt = self.args.time_steps + 1
         self.dec = decoder.GridDecoder(self.Nt, self.g["U_modes"], copy.deepcopy(self.model), self.g["mean"], self.g["std"],
                                        dtype=torch.bfloat16, device=self.dev)
+        assert self.dec.plan is not None, "the committed decoder must take the one-kernel form (bg_decode_mlp_bf16)"
         self.mu1d, self.mu2d = torch.as_tensor(self.mu1, device=self.dev), torch.as_tensor(self.mu2, device=self.dev)
         self.chunk = 1024                                  # samples per contraction: the fp64 result block is 2.1 GB
 
@@ -462,8 +463,9 @@ class DecoderWorkload(Workload):
         per_col = 512 * 8 + 160 * 2                        # the fp64 snapshot column written + its bf16 coefficients read
         gbs = units * per_col / kernel_s / 1e9
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "decode_modes_kernel<10> (bg_decode_modes_bf16: bf16 MFMA contraction, float64 result written "
-                                           "once) after the PyTorch-ROCm bf16 MLP (rocBLAS GEMMs + ELU), which the config prescribes",
+                "traffic": None, "kernel": "decode_mlp_kernel<10, 8> (bg_decode_mlp_bf16: the bf16 MLP evaluated per 128-column workgroup "
+                                           "inside the contraction kernel -- bitwise the PyTorch-ROCm bf16 module's coefficients -- then the "
+                                           "bf16 MFMA contraction, float64 result written once; no activation or coefficient crosses HBM)",
                 "pass_ms_avg": kernel_s * 1e3, "algorithmic_bytes_per_column": per_col}
 
 

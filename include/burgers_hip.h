@@ -369,6 +369,23 @@ int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, co
  *   N a multiple of 32, n a multiple of 16, n <= 256 (BG_ERR_UNSUPPORTED_N / _R otherwise: use a library GEMM). */
 int bg_decode_modes_bf16(int N, int n, int B, int Nt, const uint16_t *Um, const uint16_t *Q, double *out, void *stream);
 
+/* bg_decode_mlp_bf16 -- the whole non-intrusive decoder in ONE kernel: MLP + contraction (bf16 tier of BASELINE config 5)
+ *   reference: Non-Instrusive/predict_pod_ann.py:60-80 (standardised (mu1, mu2, t) -> model -> Qhat -> U_modes @ Qhat.T)
+ *   A workgroup evaluates the MLP for its own 128 (sample, time level) columns -- activations as bf16 in LDS, bf16 MFMA with
+ *   float32 accumulate, the rounding points of the PyTorch bf16 module (Linear output -> bf16, activation in float32 -> bf16)
+ *   -- and contracts them with U_modes as bg_decode_modes_bf16 does: no activation or coefficient ever crosses HBM.
+ *     z1 [B], z2 [B]  standardised mu1, mu2 (float64; rounded to bf16 through float32 in the kernel, as `.to(bfloat16)`)
+ *     ztau [Nt]       standardised time levels
+ *     layer l (host arrays of n_layers entries; DEVICE pointers inside):
+ *       W[l]     [wout[l]][win[l]] bf16 row-major = torch Linear.weight zero padded: win[0] = 16 (the 3 inputs padded),
+ *                win[l] = wout[l-1], every wout a multiple of 32 (padding features: zero rows, zero bias), wout[last] = n
+ *       bias[l]  [wout[l]] bf16 or NULL;  acts[l] BG_ACT_* after layer l, alphas[l] its ELU alpha
+ *   Um [N][n] bf16, out [B][N][Nt] float64.  N a multiple of 32, n a multiple of 32, widths <= 256, n_layers <= 8
+ *   (BG_ERR_UNSUPPORTED_N / _R otherwise: run the model in PyTorch and call bg_decode_modes_bf16). */
+int bg_decode_mlp_bf16(int N, int n, int B, int Nt, const uint16_t *Um, const double *z1, const double *z2, const double *ztau,
+                       int n_layers, const int *win, const int *wout, const uint16_t *const *W, const uint16_t *const *bias,
+                       const int *acts, const float *alphas, double *out, void *stream);
+
 /* bg_jacobi_sweep -- n_steps steps of a one-sided (Hestenes) Jacobi SVD sweep, the accurate small core of
  * the snapshot SVD (reference: np.linalg.svd at POD/pod.py:84, build_quadratic_manifold.py:29).
  *   G      [m][ld] row-major: the m rows are orthogonalised in place by plane rotations

@@ -290,6 +290,62 @@ def test_nonintrusive_decoder_fp32_and_bf16(hip):
     assert 1e-3 < err < 3.5e-2, err
 
 
+def _decoder_model(g, dims=(3, 32, 64, 128, 160)):
+    import torch.nn as nn
+    layers = []
+    for i, key in enumerate((0, 2, 4, 6)):
+        lin = nn.Linear(dims[i], dims[i + 1])
+        with torch.no_grad():
+            lin.weight.copy_(torch.from_numpy(g[f"{key}_weight"])); lin.bias.copy_(torch.from_numpy(g[f"{key}_bias"]))
+        layers.append(lin)
+        if i < 3:
+            layers.append(nn.ELU())
+    return nn.Sequential(*layers).eval()
+
+
+def test_decoder_mlp_in_kernel_matches_the_pytorch_bf16_module(hip):
+    """bg_decode_mlp_bf16 (MLP + contraction in one kernel) against the PyTorch bf16 module followed by
+    bg_decode_modes_bf16: same rounding points (Linear output -> bf16, ELU in float32 -> bf16), so what differs is the
+    summation order inside the float32 accumulators -- a coefficient that lands on the other side of a bf16 rounding
+    boundary moves by 2^-8 relative.  Measured 1.5e-3 relative L2 between the two; both sit at the same distance from the
+    float32 reference (the bf16 tier's own error, 6e-3 .. 1.7e-2)."""
+    import copy
+    from burgers_hip import decoder
+    g = load_golden("nonintrusive_decoder.npz")
+    model = _decoder_model(g)
+    rng = np.random.default_rng(5)
+    mu1, mu2 = rng.uniform(4.25, 5.5, 37), rng.uniform(0.015, 0.03, 37)          # 37 x 501 columns: a ragged last workgroup
+    mu1[0], mu2[0] = float(g["mu1"]), float(g["mu2"])
+    Nt = int(g["Nt"])
+    dec = decoder.GridDecoder(Nt, g["U_modes"], copy.deepcopy(model), g["mean"], g["std"], dtype=torch.bfloat16)
+    assert dec.plan is not None, "the committed decoder is a plain MLP: it must take bg_decode_mlp_bf16"
+    ref = decoder.GridDecoder(Nt, g["U_modes"], copy.deepcopy(model), g["mean"], g["std"], dtype=torch.bfloat16, fused=False)
+    assert ref.plan is None
+    U, V = dec.predict(mu1, mu2), ref.predict(mu1, mu2)
+    assert U.shape == V.shape == (37, 512, Nt) and torch.isfinite(U).all()
+    assert rel_l2(U.cpu().numpy(), V.cpu().numpy()) < 5e-3
+    F = decoder.GridDecoder(Nt, g["U_modes"], copy.deepcopy(model), g["mean"], g["std"]).predict(mu1, mu2)   # float32 tier
+    eu, ev = rel_l2(U.cpu().numpy(), F.cpu().numpy()), rel_l2(V.cpu().numpy(), F.cpu().numpy())
+    assert eu < 2e-2 and ev < 2e-2 and eu < 1.5 * ev + 1e-3, (eu, ev)
+    # the committed reference prediction (nine columns of the training sample, float64 modes @ float32 MLP)
+    assert rel_l2(U[0].cpu().numpy()[:, g["cols"]], g["Uhat_cols"]) < 3.5e-2
+    # chunking the batch does not change a bit: a column depends on its own (mu1, mu2, t) only
+    assert torch.equal(dec.predict(mu1[5:19], mu2[5:19]), U[5:19])
+    # a model the in-kernel form does not cover falls back to the PyTorch module (odd width)
+    odd = torch.nn.Sequential(torch.nn.Linear(3, 20), torch.nn.ELU(), torch.nn.Linear(20, 160)).eval()
+    d2 = decoder.GridDecoder(Nt, g["U_modes"], odd, g["mean"], g["std"], dtype=torch.bfloat16)
+    assert d2.plan is not None        # widths are padded to 32 on the host: 20 -> 32 with zero rows
+    W = d2.predict(mu1[:3], mu2[:3])
+    W0 = decoder.GridDecoder(Nt, g["U_modes"], odd, g["mean"], g["std"], dtype=torch.bfloat16, fused=False).predict(mu1[:3], mu2[:3])
+    assert rel_l2(W.cpu().numpy(), W0.cpu().numpy()) < 1e-2
+    class Gated(torch.nn.Module):
+        def __init__(self):
+            super().__init__(); self.a = torch.nn.Linear(3, 160)
+        def forward(self, x):
+            return self.a(x) * torch.sigmoid(x[:, :1])
+    assert decoder.GridDecoder(Nt, g["U_modes"], Gated().eval(), g["mean"], g["std"], dtype=torch.bfloat16).plan is None
+
+
 def test_pod_rbf_prom_live_reference(hip):
     """Widening row f.3: pod_rbf_prom with a 300-centre closure; both kernels, both projections.
     The closure weights reach 3.6e2, which amplifies rounding in the decoder: tolerance 1e-9."""
