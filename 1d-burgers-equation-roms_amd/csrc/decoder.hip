@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void decode_mlp_kernel(const uint16_t* __re
     // one is multiplied and activated: they do not depend on the activations, so the prefetch crosses layer boundaries.
     // No branches inside: fragments beyond a layer's inputs re-read its last 16 (a cache hit) and meet zero B fragments --
     // 35 idle matrix instructions per 244 at the committed widths, against one exposed L2 round trip per guarded load
-    // (first version, with `if (kb < nkb)` around every load + MFMA: 50 k clocks per workgroup for the MLP; now 12 k).
+    // (first version, with `if (kb < nkb)` around every load + MFMA and a divergent branch around expf: 0.783 ms per 1024
+    // samples; this form 0.697 ms; the contraction alone 0.637 ms -- DESIGN K6).
     auto fetch = [&](int l, int mt, bf16x8 (&a)[MAXKB], uint2 (&bz)[4]) {
         const int win = m.win[l], nkb = win >> 4;
         const uint16_t* wrow = m.W[l] + (size_t)(32 * mt + lr) * win + 8 * lh;
