@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 kload(kb, wa);
                 kfma(kb, wa);
             }
+            if constexpr (skip(8192)) lap(3);                          // (8192: timing only: sub-phases of a layer summed over the layers)
             // fold the KPw input slices (lanes P apart): inside a row of 16 lanes with shifts towards the higher lanes, so
             // the row total lands in its last P lanes; across the four rows with ds_bpermute
             auto fold = [&](auto get) {
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                     d = 1.0f - av * av;
                 }
             };
+            if constexpr (skip(8192)) lap(4);
             const bool swapfold = (NRT == 6 || NRT == 1) && span == 64 && !skip(2048);      // workgroup-uniform
             if (swapfold) {
                 // Across the four rows of 16 lanes with v_permlane16_swap / v_permlane32_swap (VALU; ds_bpermute would make
@@ -345,7 +347,9 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                     }
                 }
             }
+            if constexpr (skip(8192)) lap(5);
             __syncthreads();
+            if constexpr (skip(8192)) lap(6);
             cur ^= 1;
             if (!swapfold) {                                          // second stage, one output per thread
                 if (tid < ldw && !skip(4096)) {
@@ -361,7 +365,8 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 }
                 __syncthreads();
             }
-            if constexpr (kTiming) {
+            if constexpr (skip(8192)) lap(7);
+            else if constexpr (kTiming) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     if (i == l) lap(3 + i);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Time bg_ann_rom_run alone (HIP events) on one MI355X: microseconds per sample-iteration per workgroup slot.
 With BG_LIB_PATH pointing at an ablation build (-DBG_FUSED_ABLATE=bits: 1 MFMA pass, 2 elimination, 16 assembly,
-128 MLP layers, 256 closure sweep) the iteration count is fixed at 5 per time step, so builds can be subtracted.
+128 MLP layers, 256 closure sweep; 8192: the "mlp layer 0..4" lines then are sub-phases summed over the layers --
+loads + FMAs, DPP folds, swap fold + activation + write, barrier wait, second stage) the iteration count is fixed at 5 per time step, so builds can be subtracted.
 usage: python tools/time_ann_fused.py [--batch 512] [--steps 20] [--proj LSPG|Galerkin] [--fused 0|1]"""
 import argparse, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
