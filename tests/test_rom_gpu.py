@@ -346,6 +346,60 @@ def test_decoder_mlp_in_kernel_matches_the_pytorch_bf16_module(hip):
     assert decoder.GridDecoder(Nt, g["U_modes"], Gated().eval(), g["mean"], g["std"], dtype=torch.bfloat16).plan is None
 
 
+@pytest.mark.parametrize("acts", [("relu", "tanh", "none"), ("elu", "none")])
+def test_decode_mlp_c_abi_random_models_and_refusals(hip, acts):
+    """bg_decode_mlp_bf16 through the C ABI on random networks (every activation kind, a 256-wide layer = the sixteen-
+    fragment instantiation, a ragged last workgroup) against a PyTorch emulation with the same rounding points; refusals."""
+    import ctypes
+    from burgers_hip import lib as L_
+    L = L_.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cuda").manual_seed(len(acts))
+    N, n, B, Nt = 64, 64, 3, 77
+    widths = [16, 256, 96, n] if len(acts) == 3 else [16, 32, n]            # padded input width first
+    kinds = {"none": hip.BG_ACT_NONE, "elu": hip.BG_ACT_ELU, "relu": hip.BG_ACT_RELU, "tanh": hip.BG_ACT_TANH}
+    bf = lambda t: t.to(torch.bfloat16)
+    Ws = [bf(torch.randn((widths[i + 1], widths[i]), device="cuda", generator=g) / widths[i] ** 0.5) for i in range(len(acts))]
+    Ws[0][:, 3:] = 0                                                        # three real inputs
+    bs = [bf(0.1 * torch.randn((widths[i + 1],), device="cuda", generator=g)) for i in range(len(acts))]
+    Um = bf(torch.randn((N, n), device="cuda", generator=g))
+    z1 = torch.randn((B,), dtype=torch.float64, device="cuda", generator=g)
+    z2 = torch.randn((B,), dtype=torch.float64, device="cuda", generator=g)
+    zt = torch.linspace(-1.7, 1.7, Nt, dtype=torch.float64, device="cuda")
+    out = torch.full((B, N, Nt), -7.0, dtype=torch.float64, device="cuda")
+    nl = len(acts)
+    arr = lambda ty, v: (ty * nl)(*v)
+    args = (arr(ctypes.c_int, widths[:-1]), arr(ctypes.c_int, widths[1:]), arr(ctypes.c_void_p, [w.data_ptr() for w in Ws]),
+            arr(ctypes.c_void_p, [b.data_ptr() for b in bs]), arr(ctypes.c_int, [kinds[a] for a in acts]), arr(ctypes.c_float, [1.0] * nl))
+    L_.check(L.bg_decode_mlp_bf16(N, n, B, Nt, L_.ptr(Um), L_.ptr(z1), L_.ptr(z2), L_.ptr(zt), nl, *args, L_.ptr(out),
+                                  L_.stream_ptr(dev)), "bg_decode_mlp_bf16")
+    torch.cuda.synchronize()
+    # the same network with the same rounding points: bf16 operands, float32 accumulate, Linear output -> bf16, activation in float32 -> bf16
+    x = torch.zeros((B * Nt, 16), dtype=torch.float32, device="cuda")
+    x[:, 0] = bf(z1.float())[:, None].expand(B, Nt).reshape(-1).float()
+    x[:, 1] = bf(z2.float())[:, None].expand(B, Nt).reshape(-1).float()
+    x[:, 2] = bf(zt.float())[None, :].expand(B, Nt).reshape(-1).float()
+    fn = {"none": lambda v: v, "elu": torch.nn.functional.elu, "relu": torch.relu, "tanh": torch.tanh}
+    for W, b, a in zip(Ws, bs, acts):
+        x = bf(fn[a](bf(x @ W.float().t() + b.float()).float())).float()
+    ref = torch.matmul(Um.double(), x.double().reshape(B, Nt, n).transpose(1, 2))
+    # a float32 summation-order difference may move a bf16 rounding by one unit in the last place (2^-8 relative) somewhere
+    assert float((out - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    assert float(torch.linalg.norm(out - ref) / torch.linalg.norm(ref)) < 2e-3
+    z = ctypes.c_void_p(0)
+    one = lambda ty, v: (ty * 1)(v)
+    vp = one(ctypes.c_void_p, Ws[0].data_ptr())
+    call = lambda N_, n_, B_, win, wout: L.bg_decode_mlp_bf16(N_, n_, B_, 1, z, z, z, z, 1, one(ctypes.c_int, win), one(ctypes.c_int, wout),
+                                                            vp, vp, one(ctypes.c_int, 0), one(ctypes.c_float, 1.0), z, z)
+    assert call(33, 32, 1, 16, 32) == hip.BG_ERR_UNSUPPORTED_N
+    assert call(32, 48, 1, 16, 48) == hip.BG_ERR_UNSUPPORTED_R             # n not a multiple of 32
+    assert call(32, 32, 1, 16, 512) == hip.BG_ERR_UNSUPPORTED_R            # wider than 256
+    assert call(32, 32, 1, 32, 32) == hip.BG_ERR_BAD_ARG                   # the first layer reads the 16 padded inputs
+    assert call(32, 32, 1, 16, 64) == hip.BG_ERR_BAD_ARG                   # the last layer must produce n coefficients
+    assert call(32, 32, 1, 16, 32) == hip.BG_ERR_BAD_ARG                   # null operands
+    assert call(32, 32, 0, 16, 32) == hip.BG_OK                            # empty batch
+
+
 def test_pod_rbf_prom_live_reference(hip):
     """Widening row f.3: pod_rbf_prom with a 300-centre closure; both kernels, both projections.
     The closure weights reach 3.6e2, which amplifies rounding in the decoder: tolerance 1e-9."""
