@@ -462,8 +462,11 @@ class DecoderWorkload(Workload):
     def roofline(self, units, kernel_s):
         per_col = 512 * 8 + 160 * 2                        # the fp64 snapshot column written + its bf16 coefficients read
         gbs = units * per_col / kernel_s / 1e9
+        tr = measured_traffic(self.kind, self.args)         # per LAUNCH = per chunk of samples; a pass is batch / chunk launches
+        nlaunch = -(-self.args.batch // self.chunk)
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "decode_mlp_kernel<10, 8> (bg_decode_mlp_bf16: the bf16 MLP evaluated per 128-column workgroup "
+                "traffic": tr["bytes"] * nlaunch if tr else None,
+                **({"traffic_source": tr["source"] + f"; x {nlaunch} launches per pass"} if tr else {}), "kernel": "decode_mlp_kernel<10, 8> (bg_decode_mlp_bf16: the bf16 MLP evaluated per 128-column workgroup "
                                            "inside the contraction kernel -- bitwise the PyTorch-ROCm bf16 module's coefficients -- then the "
                                            "bf16 MFMA contraction, float64 result written once; no activation or coefficient crosses HBM)",
                 "pass_ms_avg": kernel_s * 1e3, "algorithmic_bytes_per_column": per_col}

@@ -23,9 +23,10 @@ with open(sys.argv[2], "w", newline="") as g:
 PY
 grep -h '"metric"' $W/kt.log | tail -1 > $O/r03_bench_default_under_profiler.json || true
 echo "kernel trace done"
-for cfg in ${CONFIGS:-pod_galerkin pod_lspg quadratic ann pod_r96_galerkin pod_r96_lspg}; do
+for cfg in ${CONFIGS:-pod_galerkin pod_lspg quadratic ann pod_r96_galerkin pod_r96_lspg decoder_bf16}; do
   case $cfg in
     pod_r96_*) key="rom_wide_kernel"; ts=40;;
+    decoder_bf16) key="decode_mlp_kernel"; ts=500;;
     pod_*) key="rom_fused_kernel"; ts=40;;
     quadratic) key="quad_fused_kernel"; ts=40;;
     ann) key="rom_ann_fused_kernel"; ts=40;;
@@ -42,9 +43,10 @@ d=json.loads(sys.stdin.read()); print(json.dumps({k: d[k] for k in ('value','ms_
 done
 # HBM traffic of the hot kernel at the FULL bench configuration (what bench.py reports as roofline.traffic of these configs)
 if [ -z "$NO_FULL_TRAFFIC" ]; then
-for cfg in ${CONFIGS:-pod_galerkin pod_lspg quadratic ann pod_r96_galerkin pod_r96_lspg}; do
+for cfg in ${CONFIGS:-pod_galerkin pod_lspg quadratic ann pod_r96_galerkin pod_r96_lspg decoder_bf16}; do
   case $cfg in
     pod_r96_*) key="rom_wide_kernel";;
+    decoder_bf16) key="decode_mlp_kernel";;
     pod_*) key="rom_fused_kernel";;
     quadratic) key="quad_fused_kernel";;
     ann) key="rom_ann_fused_kernel";;
