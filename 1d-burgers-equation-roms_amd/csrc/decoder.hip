@@ -27,6 +27,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int DEC_COLS = 128;        // columns per workgroup
 constexpr int DEC_MAX_KB = 16;       // n <= 256
 
+// XCD-aware order of the 128-column chunks.  Workgroups go round-robin to the 8 XCDs (each with its own L2), so with
+// chunk = blockIdx the four chunks that make up the 4-KB rows of ONE sample are written through four different L2s at
+// unrelated times; chunk = (blockIdx % 8) * (chunks per XCD) + blockIdx / 8 puts neighbouring chunks on the same XCD in
+// neighbouring dispatch slots: one L2 sees a row's pieces together.  As pure stores (tools/store_pattern_bench.hip,
+// 2.1 GB): 2.97 -> 3.64 TB/s for this tile shape; 64 KB contiguous per workgroup reaches 5.3 -- 5.7, out of reach here
+// (the coefficients of all 501 columns of a sample do not fit LDS: 164 KB).
+__device__ __forceinline__ long long xcd_chunk(long long C)
+{
+    const long long per = (gridDim.x + 7) / 8;
+    (void)C;
+    return (long long)(blockIdx.x % 8) * per + blockIdx.x / 8;
+}
+
 // The contraction proper, shared by the two kernels: s_q holds the workgroup's 128 coefficient rows ([DEC_COLS][LD] bf16), the
 // caller has synchronised.
 template <int KB>
@@ -46,6 +59,7 @@ __device__ __forceinline__ void decode_tiles(const uint16_t* __restrict__ Um, co
         o1 = cb < C ? bb * (long long)N * Nt + (cb - bb * Nt) : -1;
     }
     const bool pair = o0 >= 0 && o1 == o0 + 1;      // both columns in the same sample: one 16-byte store per row
+    const bool all_pair = __ballot(pair) == ~0ull;  // no sample boundary and no ragged end inside this wave's 128 columns
     for (int it = w; it < N / 32; it += 4) {
         const int i0 = 32 * it;
         bf16x8 a[KB];
@@ -73,15 +87,24 @@ __device__ __forceinline__ void decode_tiles(const uint16_t* __restrict__ Um, co
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (all_pair) {                              // (wave-uniform) the common case: eight reads in flight, eight stores
+                double2 val[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const double2 val = *reinterpret_cast<const double2*>(&stage[r * DEC_COLS + 2 * lane]);
-                const long long ro = (long long)(i0 + 8 * v4 + r) * Nt;
-                if (pair) {
-                    *reinterpret_cast<double2*>(out + o0 + ro) = val;       // 8-byte aligned: see above
-                } else {
-                    if (o0 >= 0) out[o0 + ro] = val.x;
-                    if (o1 >= 0) out[o1 + ro] = val.y;
+                for (int r = 0; r < 8; ++r) val[r] = *reinterpret_cast<const double2*>(&stage[r * DEC_COLS + 2 * lane]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    *reinterpret_cast<double2*>(out + o0 + (long long)(i0 + 8 * v4 + r) * Nt) = val[r];   // 8-byte aligned: see above
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const double2 val = *reinterpret_cast<const double2*>(&stage[r * DEC_COLS + 2 * lane]);
+                    const long long ro = (long long)(i0 + 8 * v4 + r) * Nt;
+                    if (pair) {
+                        *reinterpret_cast<double2*>(out + o0 + ro) = val;
+                    } else {
+                        if (o0 >= 0) out[o0 + ro] = val.x;
+                        if (o1 >= 0) out[o1 + ro] = val.y;
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -103,7 +126,8 @@ __global__ __launch_bounds__(256, 2) void decode_modes_kernel(const uint16_t* __
     // the time axis, 16 bytes per lane (the row pitch Nt * 8 = 4008 bytes leaves the runs 8-byte aligned only; the hardware
     // splits the few lanes that straddle a line).
     double* stage = reinterpret_cast<double*>(s_q + DEC_COLS * LD) + w * (8 * DEC_COLS);
-    const long long c0 = (long long)blockIdx.x * DEC_COLS;
+    const long long c0 = xcd_chunk(C) * DEC_COLS;
+    if (c0 >= C) return;                                         // (the grid is rounded up to a multiple of 8)
     // the workgroup's coefficient rows (zero beyond the last column)
     for (int e = tid; e < DEC_COLS * (n / 8); e += 256) {
         const int col = e / (n / 8), ch = e - col * (n / 8);
@@ -119,7 +143,7 @@ template <int KB>
 int launch_decode(const uint16_t* Um, const uint16_t* Q, double* out, int N, int Nt, long long C, hipStream_t st)
 {
     const size_t lds = (size_t)DEC_COLS * (16 * KB + 8) * sizeof(uint16_t) + 4 * 8 * DEC_COLS * sizeof(double);
-    const long long grid = (C + DEC_COLS - 1) / DEC_COLS;
+    const long long grid = ((C + DEC_COLS - 1) / DEC_COLS + 7) / 8 * 8;      // see xcd_chunk
     if (lds > 64 * 1024) {                   // beyond the default dynamic-LDS limit: raise it once per instantiation and device
         static std::atomic<unsigned> done{0};
         int dev = 0;
@@ -176,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void decode_mlp_kernel(const uint16_t* __re
     extern __shared__ __attribute__((aligned(16))) uint16_t s_q[];   // [DEC_COLS][LD] (LD >= every layer width + 8), then the staging rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double* stage = reinterpret_cast<double*>(s_q + DEC_COLS * LD) + w * (8 * DEC_COLS);
-    const long long c0 = (long long)blockIdx.x * DEC_COLS;
+    const long long c0 = xcd_chunk(C) * DEC_COLS;
+    if (c0 >= C) return;                                         // (the grid is rounded up to a multiple of 8)
     const int lr = lane & 31, lh = lane >> 5;
     uint16_t* myrow = s_q + (32 * w + lr) * LD;                       // this lane's column of the workgroup's 128
     // ---- the network input of this lane's column: bf16(z1[b]), bf16(z2[b]), bf16(ztau[t]), zeros up to 16 ----------------------
@@ -283,7 +308,7 @@ template <int KB, int MAXKB>
 int launch_decode_mlp(const uint16_t* Um, const DecMlpArgs& m, double* out, int N, int Nt, long long C, int LD, hipStream_t st)
 {
     const size_t lds = (size_t)DEC_COLS * LD * sizeof(uint16_t) + 4 * 8 * DEC_COLS * sizeof(double);
-    const long long grid = (C + DEC_COLS - 1) / DEC_COLS;
+    const long long grid = ((C + DEC_COLS - 1) / DEC_COLS + 7) / 8 * 8;      // see xcd_chunk
     if (lds > 64 * 1024) {                   // beyond the default dynamic-LDS limit: raise it (per instantiation; idempotent)
         static std::atomic<int> granted[32];
         int dev = 0;
