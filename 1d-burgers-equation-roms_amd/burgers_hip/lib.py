@@ -80,19 +80,19 @@ _SIGNATURES = {
     "bg_rom_run_max_r": (ctypes.c_int, []),
     "bg_rom_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                   c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                                  ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
+                                  ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
     "bg_quad_rom_max_n": (ctypes.c_int, []),
     "bg_quad_rom_h3f_elems": (ctypes.c_longlong, [ctypes.c_int]),
     "bg_quad_rom_phif_elems": (ctypes.c_longlong, [ctypes.c_int]),
     "bg_quad_rom_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                        c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p,
-                                       ctypes.c_void_p]),
+                                       c_int_p, ctypes.c_void_p]),
     "bg_rom_run_wide_max_r": (ctypes.c_int, []),
     "bg_rom_run_wide_phi_elems": (ctypes.c_longlong, [ctypes.c_int]),
     "bg_rom_run_wide": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                        c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                                       ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
+                                       ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
     "bg_rom_lift": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                    c_int_p, c_double_p, ctypes.c_void_p]),
     "bg_quad_features": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_double_p, ctypes.c_void_p]),
@@ -130,7 +130,7 @@ _SIGNATURES = {
                                       ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
                                       ctypes.POINTER(ctypes.c_float), ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                                      ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
+                                      ctypes.c_int, ctypes.c_int, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, ctypes.c_void_p]),
 }
 
 _lib = None
@@ -194,7 +194,7 @@ def require_device(device=None):
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(None if t is None else t.data_ptr())
 
 
 def stream_ptr(device):

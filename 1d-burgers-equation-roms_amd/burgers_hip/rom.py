@@ -251,7 +251,7 @@ def _workspace(c, r):
 
 
 # --------------------------------------------------------------------------- POD
-def pod_prom_run_fused(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E=0.0, tol=1e-6, max_it=20, device=None, options=0):
+def pod_prom_run_fused(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E=0.0, tol=1e-6, max_it=20, device=None, options=0, balance=True):
     """``pod_prom_burgers`` for a batch with the whole time loop on the device (bg_rom_run): one workgroup per
     sample, no host in the loop.  Covers N <= 512 and r <= bg_rom_run_max_r()."""
     L = _lib.load()
@@ -269,17 +269,49 @@ def pod_prom_run_fused(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E=0.0, tol=1e-6, 
     iters = torch.zeros((B, nsteps), dtype=torch.int32, device=device)
     flags = torch.zeros((B,), dtype=torch.int32, device=device)
     info = torch.zeros((B,), dtype=torch.int32, device=device)
+    order = sample_order(mu1d, 2 * _cu_count(device)) if balance else None
     with torch.cuda.device(device):
         rc = L.bg_rom_run(N, B, r, int(nsteps), proj, _lib.ptr(Xd), _lib.ptr(Phid), _lib.ptr(u0d), _lib.ptr(mu1d),
                           _lib.ptr(mu2d), float(dt), float(E), float(tol), int(max_it), int(opts), _lib.ptr(hist),
-                          _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(info), _lib.stream_ptr(device))
+                          _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(info), _lib.ptr(order), _lib.stream_ptr(device))
     _lib.check(rc, "bg_rom_run")
     res = FomResult(hist, iters, flags)
     res.info = info              # checked lazily by the facade (a readback would synchronise)
     return res
 
 
-def pod_prom_run_wide(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E=0.0, tol=1e-6, max_it=20, device=None, PhiP=None, options=0):
+def sample_order(mu1d, grid, group=1):
+    """The ``order`` argument of the device-side time loops (bg_rom_run, bg_rom_run_wide, bg_quad_rom_run,
+    bg_ann_rom_run): which sample each slot of the launch works on.  The samples are independent, so this is a pure
+    scheduling decision -- the results are the same bit for bit -- but their cost is not uniform: the iteration count of
+    a sample follows its convection parameter mu1 (correlation 0.99 on the bench sweep).  Workgroup k of ``grid``
+    persistent workgroups takes the slots k, k + grid, ...; with ``group`` = 4 (bg_quad_rom_run) four consecutive slots
+    share a workgroup and every pass lasts until the slowest of the four has converged.  So: sort by mu1, keep
+    neighbours together inside a group, and deal the groups out in boustrophedon order (round 0 left to right, round 1
+    right to left, ...) so that every workgroup gets the same mix of expensive and cheap ones.  Returns an int32
+    device tensor, or None when there is nothing to balance."""
+    B = mu1d.numel()
+    units = B // group                                   # whole groups; a ragged tail keeps the last slots
+    if B <= group or (group == 1 and B <= grid):
+        return None
+    rank = torch.argsort(mu1d, descending=True)
+    u = torch.arange(units, device=mu1d.device)
+    rnd, pos = u // grid, u % grid
+    size = torch.clamp(units - rnd * grid, max=grid)      # units in this round (the last one may be short)
+    slot = rnd * grid + torch.where(rnd % 2 == 0, pos, size - 1 - pos)
+    order = torch.empty_like(rank)
+    head = units * group
+    order[:head].view(units, group)[slot] = rank[:head].view(units, group)
+    order[head:] = rank[head:]
+    return order.to(torch.int32)
+
+
+def _cu_count(device):
+    return torch.cuda.get_device_properties(device).multi_processor_count
+
+
+def pod_prom_run_wide(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E=0.0, tol=1e-6, max_it=20, device=None, PhiP=None, options=0,
+                      balance=True):
     """``pod_prom_burgers`` for bases of 41 .. 96 modes with the whole time loop on the device (bg_rom_run_wide): the basis
     streams through LDS, the reduced system's accumulators are spread over the four waves of the sample's workgroup.
     Samples whose elimination would have needed a row exchange come back marked and are redone through the library
@@ -304,10 +336,11 @@ def pod_prom_run_wide(X, u0, mu1, mu2, dt, nsteps, Phi, proj, E=0.0, tol=1e-6, m
     iters = torch.zeros((B, nsteps), dtype=torch.int32, device=device)
     flags = torch.zeros((B,), dtype=torch.int32, device=device)
     info = torch.zeros((B,), dtype=torch.int32, device=device)
+    order = sample_order(mu1d, _cu_count(device)) if balance else None
     with torch.cuda.device(device):
         rc = L.bg_rom_run_wide(N, B, r, int(nsteps), proj, _lib.ptr(Xd), _lib.ptr(PhiP), _lib.ptr(u0d), _lib.ptr(mu1d),
                                _lib.ptr(mu2d), float(dt), float(E), float(tol), int(max_it), int(opts), _lib.ptr(hist),
-                               _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(info), _lib.stream_ptr(device))
+                               _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(info), _lib.ptr(order), _lib.stream_ptr(device))
     _lib.check(rc, "bg_rom_run_wide")
     redo = (info == _lib.BG_INFO_NEEDS_PIVOTING).nonzero().squeeze(1)
     if redo.numel():                                     # rare: np.linalg.solve would have exchanged rows
@@ -500,7 +533,8 @@ class QuadFusedPlan:
         assert self.H3f.numel() == L.bg_quad_rom_h3f_elems(N) and self.Phif.numel() == L.bg_quad_rom_phif_elems(N)
 
 
-def quadratic_run_fused(X, u0, mu1, mu2, dt, nsteps, plan, proj, E=0.0, newton_tol=1e-6, newton_itmax=25, device=None):
+def quadratic_run_fused(X, u0, mu1, mu2, dt, nsteps, plan, proj, E=0.0, newton_tol=1e-6, newton_itmax=25, device=None,
+                        balance=True):
     """``pod_quadratic_manifold`` for a batch with the whole time loop on the device (bg_quad_rom_run): four samples
     per workgroup, no host in the loop; the reduced solve pivots like np.linalg.solve."""
     L = _lib.load()
@@ -516,11 +550,12 @@ def quadratic_run_fused(X, u0, mu1, mu2, dt, nsteps, plan, proj, E=0.0, newton_t
     iters = torch.zeros((B, nsteps), dtype=torch.int32, device=device)
     flags = torch.zeros((B,), dtype=torch.int32, device=device)
     info = torch.zeros((B,), dtype=torch.int32, device=device)
+    order = sample_order(mu1d, _cu_count(device), group=4) if balance else None
     with torch.cuda.device(device):
         rc = L.bg_quad_rom_run(N, B, plan.n, int(nsteps), proj, _lib.ptr(Xd), _lib.ptr(plan.PhiT), _lib.ptr(plan.Phif),
                                _lib.ptr(plan.H3f), _lib.ptr(u0d), _lib.ptr(mu1d), _lib.ptr(mu2d), float(dt), float(E),
                                float(newton_tol), int(newton_itmax), int(opts), _lib.ptr(hist), _lib.ptr(iters),
-                               _lib.ptr(flags), _lib.ptr(info), _lib.stream_ptr(device))
+                               _lib.ptr(flags), _lib.ptr(info), _lib.ptr(order), _lib.stream_ptr(device))
     _lib.check(rc, "bg_quad_rom_run")
     res = FomResult(hist, iters, flags)
     res.info = info              # checked lazily by the caller (a readback would synchronise)
@@ -842,7 +877,7 @@ def _ann_fused_plan(model, n, nbar, N, dtype, device):
 
 
 def pod_ann_run_fused(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, proj, E=0.0, tol=1e-6, max_it=50, device=None,
-                      options=0, plan=None):
+                      options=0, plan=None, balance=True):
     """``pod_ann_prom`` for a batch with the whole time loop on the device (bg_ann_rom_run): one workgroup per sample,
     the closure MLP evaluated in-kernel in float32, the reduced solve with partial pivoting.  Returns None when the model
     is outside what that kernel covers."""
@@ -868,11 +903,13 @@ def pod_ann_run_fused(X, u0, mu1, mu2, dt, nsteps, U_p, U_s, model, proj, E=0.0,
     iters = torch.zeros((B, nsteps), dtype=torch.int32, device=device)
     flags = torch.zeros((B,), dtype=torch.int32, device=device)
     info = torch.zeros((B,), dtype=torch.int32, device=device)
+    order = sample_order(mu1d, 2 * _cu_count(device)) if balance else None
     with torch.cuda.device(device):
         rc = L.bg_ann_rom_run(N, B, n, nbar, int(nsteps), proj, _lib.ptr(Xd), _lib.ptr(UT), _lib.ptr(u0d),
                               _lib.ptr(mu1d), _lib.ptr(mu2d), plan["nl"], plan["widths"], plan["wt"], plan["bias"],
                               plan["acts"], plan["alphas"], float(dt), float(E), float(tol), int(max_it), int(opts),
-                              _lib.ptr(hist), _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(info), _lib.stream_ptr(device))
+                              _lib.ptr(hist), _lib.ptr(iters), _lib.ptr(flags), _lib.ptr(info), _lib.ptr(order),
+                              _lib.stream_ptr(device))
     _lib.check(rc, "bg_ann_rom_run")
     res = FomResult(hist, iters, flags)
     res.info = info

@@ -73,6 +73,7 @@ struct QuadRunArgs {
     int32_t* iters;         // [B][nsteps]
     int32_t* flags;         // [B]
     int32_t* info;          // [B]
+    const int32_t* order;   // [B] or null: wave w of group g works on sample order[4 g + w] (the four share their passes)
     double dt, E, tol;
     int N, NPAD, NG, B, n, nsteps, max_it, nonuniform;
 };
@@ -109,9 +110,11 @@ __global__ __launch_bounds__(256, 1) void quad_fused_kernel(QuadRunArgs a)
     for (int e = tid; e < QG * QTJ; e += 256) s_T[e] = 0.0;        // ring slots are read before their first write (row -1 of slab 0): keep them finite
     const int ngroups = (a.B + QG - 1) / QG;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int smp = grp * QG + w;
-        const bool valid = smp < a.B;
-        const int sb = valid ? smp : a.B - 1;          // a padding wave computes on a copy of the last sample, stores nothing
+        const int slot = grp * QG + w;
+        const bool valid = slot < a.B;
+        const int slotc = valid ? slot : a.B - 1;      // a padding wave computes on a copy of the last sample, stores nothing
+        const int sb = a.order ? a.order[slotc] : slotc;
+        const int smp = sb;
         const double mu1 = a.mu1[sb], mu2 = a.mu2[sb];
         double* hist = a.hist + (size_t)sb * (size_t)(a.nsteps + 1) * (size_t)N;
         __syncthreads();                               // the previous group is done with LDS
@@ -533,7 +536,8 @@ long long bg_quad_rom_phif_elems(int N) { return N < 2 ? 0 : (long long)((N + 3)
 
 int bg_quad_rom_run(int N, int B, int n, int nsteps, int projection, const double* x, const double* PhiT, const double* Phif,
                     const double* H3f, const double* u0, const double* mu1, const double* mu2, double dt, double E, double tol,
-                    int max_it, int options, double* hist, int32_t* iters, int32_t* flags, int32_t* info, void* stream)
+                    int max_it, int options, double* hist, int32_t* iters, int32_t* flags, int32_t* info, const int32_t* order,
+                    void* stream)
 {
     if (N < 2 || B < 0 || n < 1 || nsteps < 0 || max_it < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
     if (projection != BG_PROJ_GALERKIN && projection != BG_PROJ_LSPG) return BG_ERR_PROJECTION;
@@ -543,7 +547,7 @@ int bg_quad_rom_run(int N, int B, int n, int nsteps, int projection, const doubl
     if (!x || !PhiT || !Phif || !H3f || !u0 || !mu1 || !mu2 || !hist || !flags || !info || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
     QuadRunArgs a;
     a.x = x; a.PhiT = PhiT; a.Phif = Phif; a.H3f = H3f; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters;
-    a.flags = flags; a.info = info; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.NPAD = ((N + 63) / 64) * 64; a.NG = (N + 3) / 4;
+    a.flags = flags; a.info = info; a.order = order; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.NPAD = ((N + 63) / 64) * 64; a.NG = (N + 3) / 4;
     a.B = B; a.n = n; a.nsteps = nsteps; a.max_it = max_it; a.nonuniform = (options & BG_OPT_NONUNIFORM) ? 1 : 0;
     const int cus = device_cu_count();
     const int groups = (B + QG - 1) / QG;

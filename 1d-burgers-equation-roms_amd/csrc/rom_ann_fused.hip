@@ -111,6 +111,7 @@ struct AnnRunArgs {
     int32_t* iters;         // [B][nsteps]
     int32_t* flags;         // [B]
     int32_t* info;          // [B]
+    const int32_t* order;   // [B] or null: slot i of the persistent loop works on sample order[i]
     const float* wt[ANN_MAX_LAYERS];     // layer l: W^T, [in4][ld] row-major: width[l] rounded up to 4 rows, width[l+1] to 8 columns, zero fill
     const float* bias[ANN_MAX_LAYERS];   // [width[l+1]] or null
     int width[ANN_MAX_LAYERS + 1];
@@ -490,7 +491,8 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         else { if (N == NPAD) closure_impl(std::integral_constant<int, 3>{}, T{}, decode); else closure_impl(std::integral_constant<int, 3>{}, F{}, decode); }
     };
 
-    for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
+    for (int slot = blockIdx.x; slot < a.B; slot += gridDim.x) {
+        const int smp = a.order ? a.order[slot] : slot;
         const double mu1 = a.mu1[smp], mu2 = a.mu2[smp];
         if constexpr (kTiming) tick = (long long)__builtin_amdgcn_s_memtime();
         double* hist = a.hist + (size_t)smp * (size_t)(a.nsteps + 1) * (size_t)N;
@@ -690,7 +692,7 @@ int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, co
                    const double* u0, const double* mu1, const double* mu2, int n_layers,
                    const int* widths, const float* const* wt, const float* const* bias, const int* acts,
                    const float* alphas, double dt, double E, double tol, int max_it, int options, double* hist,
-                   int32_t* iters, int32_t* flags, int32_t* info, void* stream)
+                   int32_t* iters, int32_t* flags, int32_t* info, const int32_t* order, void* stream)
 {
     if (N < 2 || B < 0 || n < 1 || nbar < 1 || nsteps < 0 || max_it < 1 || !(dt > 0.0) || n_layers < 1) return BG_ERR_BAD_ARG;
     if (projection != BG_PROJ_GALERKIN && projection != BG_PROJ_LSPG) return BG_ERR_PROJECTION;
@@ -709,7 +711,7 @@ int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, co
     if (B == 0) return BG_OK;
     if (!x || !UT || !u0 || !mu1 || !mu2 || !hist || !flags || !info || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
     a.x = x; a.UT = UT; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
-    a.info = info; a.nl = n_layers; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.B = B; a.n = n; a.nbar = nbar;
+    a.info = info; a.order = order; a.nl = n_layers; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.B = B; a.n = n; a.nbar = nbar;
     a.nsteps = nsteps; a.max_it = max_it; a.supg = options & BG_OPT_SUPG; a.nonuniform = (options & BG_OPT_NONUNIFORM) ? 1 : 0;
     a.no_reuse = (options & BG_OPT_NO_TANGENT_REUSE) ? 1 : 0;
     const int slots = 2 * device_cu_count();         // two workgroups per CU: one's memory latency hides behind the other

@@ -42,6 +42,7 @@ struct RomRunArgs {
     int32_t* iters;         // [B][nsteps]
     int32_t* flags;         // [B]
     int32_t* info;          // [B]
+    const int32_t* order;   // [B] or null: slot i of the persistent loop works on sample order[i]
     double dt, E, tol;
     int N, B, r, nsteps, max_it, supg, nonuniform, force_pivoted;
 };
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
     }
     if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;      // halos [0], [1], [NPAD+2], [NPAD+3]
 
-    for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
+    for (int slot = blockIdx.x; slot < a.B; slot += gridDim.x) {
+        const int smp = a.order ? a.order[slot] : slot;
         if (PIV && !a.force_pivoted && a.info[smp] != BG_INFO_NEEDS_PIVOTING) continue;      // workgroup-uniform
         const double mu1 = a.mu1[smp], mu2 = a.mu2[smp];
         double* hist = a.hist + (size_t)smp * (size_t)(a.nsteps + 1) * (size_t)N;
@@ -316,7 +318,7 @@ int bg_rom_run_max_r(void) { return 40; }
 
 int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double* x, const double* Phi, const double* u0,
                const double* mu1, const double* mu2, double dt, double E, double tol, int max_it, int options,
-               double* hist, int32_t* iters, int32_t* flags, int32_t* info, void* stream)
+               double* hist, int32_t* iters, int32_t* flags, int32_t* info, const int32_t* order, void* stream)
 {
     if (N < 2 || B < 0 || r < 1 || nsteps < 0 || max_it < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
     if (projection != BG_PROJ_GALERKIN && projection != BG_PROJ_LSPG) return BG_ERR_PROJECTION;
@@ -326,7 +328,7 @@ int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double* x,
     if (!x || !Phi || !u0 || !mu1 || !mu2 || !hist || !flags || !info || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
     RomRunArgs a;
     a.x = x; a.Phi = Phi; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags;
-    a.info = info; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.B = B; a.r = r; a.nsteps = nsteps; a.max_it = max_it;
+    a.info = info; a.order = order; a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.B = B; a.r = r; a.nsteps = nsteps; a.max_it = max_it;
     a.supg = options & BG_OPT_SUPG; a.nonuniform = (options & BG_OPT_NONUNIFORM) ? 1 : 0;
     a.force_pivoted = (options & BG_OPT_FORCE_PIVOTED) ? 1 : 0;
     const int cus = device_cu_count();

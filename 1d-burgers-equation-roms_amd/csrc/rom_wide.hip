@@ -49,6 +49,7 @@ struct WideRunArgs {
     int32_t* iters;         // [B][nsteps]
     int32_t* flags;         // [B]
     int32_t* info;          // [B]
+    const int32_t* order;   // [B] or null: slot i of the persistent loop works on sample order[i]
     double dt, E, tol;
     int N, NPAD, B, r, nsteps, max_it, supg, nonuniform, force_handback;
 };
@@ -337,7 +338,8 @@ __device__ __forceinline__ void rom_wide_body(const WideRunArgs& a, const WideLd
     const int nslab = (N + WRS - 1) / WRS;
     if (tid < 4) s_u[tid < 2 ? tid : NPADM + tid] = 0.0;
 
-    for (int smp = blockIdx.x; smp < a.B; smp += gridDim.x) {
+    for (int slot = blockIdx.x; slot < a.B; slot += gridDim.x) {
+        const int smp = a.order ? a.order[slot] : slot;
         const double mu1 = a.mu1[smp], mu2 = a.mu2[smp];
         double* hist = a.hist + (size_t)smp * (size_t)(a.nsteps + 1) * (size_t)N;
         __syncthreads();
@@ -586,7 +588,7 @@ long long bg_rom_run_wide_phi_elems(int N) { return N < 2 ? 0 : (long long)(((N 
 
 int bg_rom_run_wide(int N, int B, int r, int nsteps, int projection, const double* x, const double* PhiP, const double* u0,
                     const double* mu1, const double* mu2, double dt, double E, double tol, int max_it, int options,
-                    double* hist, int32_t* iters, int32_t* flags, int32_t* info, void* stream)
+                    double* hist, int32_t* iters, int32_t* flags, int32_t* info, const int32_t* order, void* stream)
 {
     if (N < 2 || B < 0 || r < 1 || nsteps < 0 || max_it < 1 || !(dt > 0.0)) return BG_ERR_BAD_ARG;
     if (projection != BG_PROJ_GALERKIN && projection != BG_PROJ_LSPG) return BG_ERR_PROJECTION;
@@ -596,7 +598,7 @@ int bg_rom_run_wide(int N, int B, int r, int nsteps, int projection, const doubl
     if (!x || !PhiP || !u0 || !mu1 || !mu2 || !hist || !flags || !info || (nsteps > 0 && !iters)) return BG_ERR_BAD_ARG;
     if ((uintptr_t)PhiP & 15) return BG_ERR_BAD_ARG;
     WideRunArgs a;
-    a.x = x; a.PhiP = PhiP; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags; a.info = info;
+    a.x = x; a.PhiP = PhiP; a.u0 = u0; a.mu1 = mu1; a.mu2 = mu2; a.hist = hist; a.iters = iters; a.flags = flags; a.info = info; a.order = order;
     a.dt = dt; a.E = E; a.tol = tol; a.N = N; a.NPAD = ((N + 63) / 64) * 64; a.B = B; a.r = r; a.nsteps = nsteps; a.max_it = max_it;
     a.supg = options & BG_OPT_SUPG; a.nonuniform = (options & BG_OPT_NONUNIFORM) ? 1 : 0;
     a.force_handback = (options & BG_OPT_FORCE_PIVOTED) ? 1 : 0;      // tests: every sample is handed back to the caller

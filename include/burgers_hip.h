@@ -230,12 +230,21 @@ int bg_lu_solve_update(int n, int B, const double *A, const double *rhs, int mod
  *   modulus the pivot is the diagonal and no search is made (first kernel).  A sample in which a multiplier exceeds 1
  *   is marked in info and redone from u0 by a second kernel of the same call with the pivot search of bg_lu_solve;
  *   that kernel returns at once when nothing is marked.  BG_OPT_FORCE_PIVOTED sends every sample through it.
+ *   order  NULL, or [B] int32 on the device: a permutation of 0 .. B-1 -- slot i of the launch works on sample order[i]
+ *          (a scheduling hint, results are the same bit for bit: the samples are independent).  The workgroups are
+ *          persistent, workgroup k of G takes the slots k, k + G, ... (G = min(B, 2 CUs); bg_rom_run_wide and
+ *          bg_ann_rom_run alike with G = min(B, CUs) / min(B, 2 CUs)); in bg_quad_rom_run the slots 4 g .. 4 g + 3 share
+ *          a workgroup AND its passes (every pass lasts until the slowest of the four has converged).  Iteration counts
+ *          follow mu1 (correlation 0.99 on the bench sweep), so a caller that sorts the samples by mu1 and deals them out
+ *          evenly (burgers_hip/rom.py::sample_order) removes the imbalance; measured at the bench sizes
+ *          (tools/time_balance.py): quadratic + 2.5 %, POD-ANN + 1.8 %, r = 96 + 2.9 %, r = 40 + 0.5 %.  The reference-side
+ *          binding passes NULL.
  * --------------------------------------------------------------------------------- */
 int bg_rom_run_max_r(void);
 int bg_rom_run(int N, int B, int r, int nsteps, int projection, const double *x, const double *Phi,
                const double *u0, const double *mu1, const double *mu2, double dt, double E, double tol,
                int max_it, int options, double *hist, int32_t *iters, int32_t *flags, int32_t *info,
-               void *stream);
+               const int32_t *order, void *stream);
 
 /* bg_rom_run_wide -- bg_rom_run for the thesis' larger bases, 40 < r <= 96 (bg_rom_run_wide_max_r), N <= 512
  *   reference: FEM/fem_burgers.py:709-785 with POD/modes/U_modes_tol_1e-04.npy (r = 96), POD/Results_thesis/prom_pod.py:35-58.
@@ -253,7 +262,7 @@ long long bg_rom_run_wide_phi_elems(int N);
 int bg_rom_run_wide(int N, int B, int r, int nsteps, int projection, const double *x, const double *PhiP,
                     const double *u0, const double *mu1, const double *mu2, double dt, double E, double tol,
                     int max_it, int options, double *hist, int32_t *iters, int32_t *flags, int32_t *info,
-                    void *stream);
+                    const int32_t *order, void *stream);
 
 /* =================================================================================
  * bg_fd_run -- batched replacement of FDBurgers.fom_burgers_newton (analytical Jacobian)
@@ -326,7 +335,7 @@ long long bg_quad_rom_phif_elems(int N);
 int bg_quad_rom_run(int N, int B, int n, int nsteps, int projection, const double *x, const double *PhiT,
                     const double *Phif, const double *H3f, const double *u0, const double *mu1, const double *mu2,
                     double dt, double E, double tol, int max_it, int options, double *hist, int32_t *iters,
-                    int32_t *flags, int32_t *info, void *stream);
+                    int32_t *flags, int32_t *info, const int32_t *order, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * bg_ann_rom_run -- batched replacement of FEMBurgers.pod_ann_prom, the WHOLE time loop on the device
@@ -359,7 +368,7 @@ int bg_ann_rom_run(int N, int B, int n, int nbar, int nsteps, int projection, co
                    const double *u0, const double *mu1, const double *mu2, int n_layers,
                    const int *widths, const float *const *wt, const float *const *bias, const int *acts,
                    const float *alphas, double dt, double E, double tol, int max_it, int options, double *hist,
-                   int32_t *iters, int32_t *flags, int32_t *info, void *stream);
+                   int32_t *iters, int32_t *flags, int32_t *info, const int32_t *order, void *stream);
 
 /* bg_decode_modes_bf16 -- the contraction of the non-intrusive POD-ANN decoder (bf16 tier of BASELINE config 5)
  *   reference: `Uhat = U_modes @ Qhat.T`, Non-Instrusive/predict_pod_ann.py:73-80, for a batch of (mu1, mu2) samples

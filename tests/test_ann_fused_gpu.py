@@ -190,10 +190,10 @@ def test_ann_fused_limits_and_edge_cases(hip):
     # C-level argument checks
     z = ctypes.c_void_p(0)
     i1 = (ctypes.c_int * 2)(5, 91); vp = (ctypes.c_void_p * 1)(None); a1 = (ctypes.c_int * 1)(0); f1 = (ctypes.c_float * 1)(1.0)
-    assert L.bg_ann_rom_run(600, 1, 5, 91, 1, 1, z, z, z, z, z, 1, i1, vp, vp, a1, f1, 0.05, 0.0, 1e-6, 50, 0, z, z, z, z, z) == hip.BG_ERR_UNSUPPORTED_N
-    assert L.bg_ann_rom_run(512, 1, 9, 91, 1, 1, z, z, z, z, z, 1, i1, vp, vp, a1, f1, 0.05, 0.0, 1e-6, 50, 0, z, z, z, z, z) == hip.BG_ERR_UNSUPPORTED_R
-    assert L.bg_ann_rom_run(512, 1, 5, 91, 1, 7, z, z, z, z, z, 1, i1, vp, vp, a1, f1, 0.05, 0.0, 1e-6, 50, 0, z, z, z, z, z) == hip.BG_ERR_PROJECTION
-    assert L.bg_ann_rom_run(512, 1, 5, 91, 1, 1, z, z, z, z, z, 1, i1, vp, vp, a1, f1, 0.05, 0.0, 1e-6, 50, 0, z, z, z, z, z) == hip.BG_ERR_BAD_ARG
+    assert L.bg_ann_rom_run(600, 1, 5, 91, 1, 1, z, z, z, z, z, 1, i1, vp, vp, a1, f1, 0.05, 0.0, 1e-6, 50, 0, z, z, z, z, z, z) == hip.BG_ERR_UNSUPPORTED_N
+    assert L.bg_ann_rom_run(512, 1, 9, 91, 1, 1, z, z, z, z, z, 1, i1, vp, vp, a1, f1, 0.05, 0.0, 1e-6, 50, 0, z, z, z, z, z, z) == hip.BG_ERR_UNSUPPORTED_R
+    assert L.bg_ann_rom_run(512, 1, 5, 91, 1, 7, z, z, z, z, z, 1, i1, vp, vp, a1, f1, 0.05, 0.0, 1e-6, 50, 0, z, z, z, z, z, z) == hip.BG_ERR_PROJECTION
+    assert L.bg_ann_rom_run(512, 1, 5, 91, 1, 1, z, z, z, z, z, 1, i1, vp, vp, a1, f1, 0.05, 0.0, 1e-6, 50, 0, z, z, z, z, z, z) == hip.BG_ERR_BAD_ARG
 
 
 def test_ann_fused_full_size_cap_pattern(hip):

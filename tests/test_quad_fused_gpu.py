@@ -129,11 +129,11 @@ def test_quad_fused_cap_nonuniform_mesh_and_edge_cases(hip):
         rom.quadratic_run(X, np.ones(512), 4.7, 0.02, 0.05, 1, c["Phi"], c["H"][:, :-1])
     L = lib.load()
     assert L.bg_quad_rom_run(600, 1, 5, 1, 1, None, None, None, None, None, None, None, 0.05, 0.0, 1e-6, 25, 0, None, None, None, None,
-                             None) == lib.BG_ERR_UNSUPPORTED_N
+                             None, None) == lib.BG_ERR_UNSUPPORTED_N
     assert L.bg_quad_rom_run(512, 1, 41, 1, 1, None, None, None, None, None, None, None, 0.05, 0.0, 1e-6, 25, 0, None, None, None, None,
-                             None) == lib.BG_ERR_UNSUPPORTED_R
+                             None, None) == lib.BG_ERR_UNSUPPORTED_R
     assert L.bg_quad_rom_run(512, 1, 5, 1, 7, None, None, None, None, None, None, None, 0.05, 0.0, 1e-6, 25, 0, None, None, None, None,
-                             None) == lib.BG_ERR_PROJECTION
+                             None, None) == lib.BG_ERR_PROJECTION
 
 
 def test_quad_fused_reduced_solve_pivots_like_numpy(hip):

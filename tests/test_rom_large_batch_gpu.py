@@ -441,3 +441,46 @@ def test_local_prom_b1200(hip):
             Uo, ito, _ = br.local_prom_burgers(X, 0.05, nT, np.ones(512), mu1[b], 0.0, mu2[b], *cl, projection=proj,
                                                return_iters=True)
             assert rel_l2(res.hist[b].cpu().numpy().T, Uo) < TOL and np.array_equal(res.iters[b].cpu().numpy(), ito)
+
+
+def test_sample_order_is_a_scheduling_hint_only(hip, quad_r40):
+    """``order`` of the device-side time loops (burgers_hip/rom.py::sample_order: samples sorted by mu1, neighbours
+    together inside a four-sample group, groups dealt out in boustrophedon order): a permutation, and the results with
+    it are bitwise those without it -- for every kernel that takes it, with more samples than persistent workgroups."""
+    from burgers_hip import rom
+    X, _ = mesh(512)
+    dev = torch.device("cuda", 0)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    rng = np.random.default_rng(17)
+    for B, grid, group in ((2 * cus * 2 + 37, 2 * cus, 1), (4 * cus + 4 * 9 + 3, cus, 4), (7, 512, 4), (5, 4, 1)):
+        mu = torch.as_tensor(rng.uniform(4.25, 5.5, B), device=dev)
+        o = rom.sample_order(mu, grid, group)
+        assert o is not None and o.dtype == torch.int32 and sorted(o.tolist()) == list(range(B))
+        if group == 4:                                    # a group holds neighbours of the mu1 ranking
+            rk = torch.empty(B, dtype=torch.long, device=dev); rk[torch.argsort(mu, descending=True)] = torch.arange(B, device=dev)
+            g = rk[o.long()][: (B // 4) * 4].view(-1, 4)
+            assert int((g.max(1).values - g.min(1).values).max()) == 3
+    assert rom.sample_order(torch.ones(3, dtype=torch.float64, device=dev), 512) is None      # nothing to balance
+    B = 2 * cus * 2 + 5
+    mu1, mu2 = rng.uniform(4.25, 5.5, B), rng.uniform(0.015, 0.03, B)
+    g40, g96 = load_golden("committed_pod_r40.npz"), load_golden("committed_pod_r96.npz")
+    u0 = np.ones(512)
+    for proj in (rom.PROJ["galerkin"], rom.PROJ["lspg"]):
+        a = rom.pod_prom_run_fused(X, u0, mu1, mu2, 0.05, 6, g40["Phi"], proj)
+        b = rom.pod_prom_run_fused(X, u0, mu1, mu2, 0.05, 6, g40["Phi"], proj, balance=False)
+        assert torch.equal(a.hist, b.hist) and torch.equal(a.iters, b.iters) and torch.equal(a.flags, b.flags)
+    Bw = cus + 9
+    a = rom.pod_prom_run_wide(X, u0, mu1[:Bw], mu2[:Bw], 0.05, 4, g96["Phi"], rom.PROJ["lspg"])
+    b = rom.pod_prom_run_wide(X, u0, mu1[:Bw], mu2[:Bw], 0.05, 4, g96["Phi"], rom.PROJ["lspg"], balance=False)
+    assert torch.equal(a.hist, b.hist) and torch.equal(a.iters, b.iters)
+    _, Phi, H = quad_r40
+    plan = rom.QuadFusedPlan(Phi, H, dev)
+    Bq = 4 * cus + 4 * 5 + 2                              # more groups than workgroups, a ragged last group
+    a = rom.quadratic_run_fused(X, u0, mu1[:Bq], mu2[:Bq], 0.05, 3, plan, rom.PROJ["lspg"])
+    b = rom.quadratic_run_fused(X, u0, mu1[:Bq], mu2[:Bq], 0.05, 3, plan, rom.PROJ["lspg"], balance=False)
+    assert torch.equal(a.hist, b.hist) and torch.equal(a.iters, b.iters) and torch.equal(a.flags, b.flags)
+    g = load_golden("ann_n5.npz")
+    model = _ann_model(g)
+    a = rom.pod_ann_run_fused(X, u0, mu1, mu2, 0.05, 3, g["U_p"], g["U_s"], model, rom.PROJ["lspg"])
+    b = rom.pod_ann_run_fused(X, u0, mu1, mu2, 0.05, 3, g["U_p"], g["U_s"], model, rom.PROJ["lspg"], balance=False)
+    assert torch.equal(a.hist, b.hist) and torch.equal(a.iters, b.iters) and torch.equal(a.flags, b.flags)
