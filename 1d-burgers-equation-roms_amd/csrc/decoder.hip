@@ -1,14 +1,18 @@
 // decoder.hip -- the contraction of the non-intrusive POD-ANN decoder, bf16 tier (BASELINE config 5, decoder-only form).
 //
-// reference: Non-Instrusive/predict_pod_ann.py:73-80, `Uhat = U_modes @ Qhat.T` for every (mu1, mu2, t) column.  The MLP that
-// produces Qhat stays in PyTorch-ROCm (bf16), as the config prescribes; this kernel is the dense product that follows it,
-// with the result written ONCE, as the float64 snapshot layout the reference returns:
-//     out[b][i][t] = sum_k Um[i][k] * Q[b * Nt + t][k]          bf16 operands, float32 accumulate (v_mfma_f32_32x32x16_bf16)
+// reference: Non-Instrusive/predict_pod_ann.py:60-80: standardised (mu1, mu2, t) -> MLP -> Qhat, then `Uhat = U_modes @ Qhat.T`
+// for every (mu1, mu2, t) column.  Two entry points:
+//   bg_decode_modes_bf16   the dense product alone (Qhat from any model, e.g. the PyTorch-ROCm bf16 module), result written
+//                          ONCE as the float64 snapshot layout the reference returns:
+//       out[b][i][t] = sum_k Um[i][k] * Q[b * Nt + t][k]      bf16 operands, float32 accumulate (v_mfma_f32_32x32x16_bf16)
+//   bg_decode_mlp_bf16     the same product with a plain MLP evaluated per workgroup in front of it (decode_mlp_kernel below):
+//                          no activation and no coefficient crosses HBM, coefficients bitwise those of the PyTorch bf16 module
 // The product is write-bound (8 N bytes per column against 2 n N flops at n = 160): a library bf16 GEMM followed by a cast
 // writes the result twice (bf16, then float64) and reads it once more, 10 N + 2 N bytes per column instead of 8 N.
 // Workgroup = 128 columns x all N rows: the columns' coefficients sit in LDS (40 KB at n = 160), a wave takes every fourth
 // 32-row tile, its A fragments (U_modes rows, L2-resident) in registers, and writes the tile through a per-wave LDS staging
-// block as runs of 128 consecutive doubles of a sample's time axis (1 KB per row, 16 bytes per lane).
+// block as runs of 128 consecutive doubles of a sample's time axis (1 KB per row, 16 bytes per lane); the chunks are dealt to the
+// XCDs so that one L2 collects the pieces of a sample's rows (xcd_chunk).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
