@@ -7,6 +7,7 @@
 //   4  one workgroup per sample, wave w writes the columns 128 w .. + 127 of every row, the four waves row by row together
 //   5  decoder tile, XCD-aware order: workgroup i works on chunk (i % 8) * (chunks / 8) + i / 8, so that the neighbouring
 //      chunks of a sample run at the same time on the SAME XCD (one L2 sees the whole 4-KB row)
+//   6  as 5 with tiles of 256 columns (2-KB runs, each wave two 1-KB stores per row)
 // build: hipcc --offload-arch=gfx950 -O3 tools/store_pattern_bench.hip -o build/store_pattern_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -34,6 +35,26 @@ __global__ __launch_bounds__(256) void store_kernel(double* __restrict__ out, lo
             const long long ro = (long long)row * Nt;
             if (PAT != 3 && pair) *reinterpret_cast<double2*>(out + o0 + ro) = make_double2(v, v);
             else { if (o0 >= 0) out[o0 + ro] = v; if (o1 >= 0) out[o1 + ro] = v; }
+        }
+    } else if (PAT == 6) {
+        const long long per = (gridDim.x + 7) / 8;
+        const long long chunk = (long long)(blockIdx.x % 8) * per + blockIdx.x / 8;
+        const long long c0 = chunk * 256;
+        if (c0 >= C) return;
+        long long o[2];
+        bool pr[2];
+        for (int h = 0; h < 2; ++h) {
+            const long long ca = c0 + 128 * h + 2 * lane, cb = ca + 1;
+            const long long ba = (ca < C ? ca : 0) / Nt, bb = (cb < C ? cb : 0) / Nt;
+            const long long o0 = ca < C ? ba * (long long)N * Nt + (ca - ba * Nt) : -1, o1 = cb < C ? bb * (long long)N * Nt + (cb - bb * Nt) : -1;
+            o[h] = o0; pr[h] = o0 >= 0 && o1 == o0 + 1;
+        }
+        for (int row = w; row < N; row += 4) {
+            const long long ro = (long long)row * Nt;
+            for (int h = 0; h < 2; ++h) {
+                if (pr[h]) *reinterpret_cast<double2*>(out + o[h] + ro) = make_double2(v, v);
+                else if (o[h] >= 0) out[o[h] + ro] = v;
+            }
         }
     } else if (PAT == 4) {
         double* p = out + (size_t)blockIdx.x * N * Nt + 128 * w + 2 * lane;               // sample = blockIdx
@@ -74,6 +95,7 @@ int main()
     run(3, store_kernel<3>, (int)((C + 127) / 128));
     run(4, store_kernel<4>, B);
     run(5, store_kernel<5>, (int)(((C + 127) / 128 + 7) / 8 * 8));
+    run(6, store_kernel<6>, (int)(((C + 255) / 256 + 7) / 8 * 8));
     CK(hipMemset(out, 0, 1024));
     return 0;
 }
