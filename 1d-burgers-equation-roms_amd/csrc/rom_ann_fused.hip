@@ -28,6 +28,12 @@ namespace {
 using namespace bg;
 using namespace bg::fused;
 
+// Issue priority of the phases (see rom_fused.hip): 3 by default, 0 in the phases named by this bit mask -- 1 the sweep
+// over [U_p | U_s], 2 the closure MLP, 4 the projection.  Measured (B = 2048): 0 (no priorities) 1.312e7, 1: 1.322e7,
+// 3: 1.329e7, 5 / 7: 1.327e7 -- the solve, assembly and update chains of one workgroup no longer queue behind the other's bulk phases.
+#ifndef BG_ANN_PRIO
+#define BG_ANN_PRIO 3
+#endif
 constexpr int ANN_MAX_LAYERS = 8;
 constexpr int ANN_MAX_WIDTH = 256;      // one thread per neuron
 constexpr int ANN_MAX_N = 8;            // reduced coordinates: two 4-column MFMA blocks
@@ -491,6 +497,9 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
         else { if (N == NPAD) closure_impl(std::integral_constant<int, 3>{}, T{}, decode); else closure_impl(std::integral_constant<int, 3>{}, F{}, decode); }
     };
 
+#if BG_ANN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     for (int slot = blockIdx.x; slot < a.B; slot += gridDim.x) {
         const int smp = a.order ? a.order[slot] : slot;
         const double mu1 = a.mu1[smp], mu2 = a.mu2[smp];
@@ -590,8 +599,17 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 if (!skip_eval) {
                     // the last evaluation of the last step feeds the decode alone: value only
                     const bool value_only = !more && step == a.nsteps - 1 && !kTiming;
+#if BG_ANN_PRIO & 2
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     mlp(value_only);
+#if BG_ANN_PRIO & 1
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     closure(decode);
+#if BG_ANN_PRIO
+                    __builtin_amdgcn_s_setprio(3);
+#endif
                     have_tangent = !value_only;
                 }
                 skip_eval = false;
@@ -619,8 +637,14 @@ __global__ __launch_bounds__(256, 2) void rom_ann_fused_kernel(AnnRunArgs a)
                 }
                 __syncthreads();
                 lap(0);
+#if BG_ANN_PRIO & 4
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 if constexpr (!skip(1))
                     mfma_pass<S, NB, GAL, 0, NB, true, RW>(frag, HaloTable<NB>{s_halo, tid}, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
+#if BG_ANN_PRIO & 4
+                __builtin_amdgcn_s_setprio(3);
+#endif
                 __syncthreads();
                 lap(1);
                 // ---- reduced solve -------------------------------------------------------------------------------

@@ -114,6 +114,13 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
     }
     if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;      // halos [0], [1], [NPAD+2], [NPAD+3]
 
+    // Issue priority (round 3).  Two workgroups share every SIMD, and the matrix instruction holds the issue port for 16
+    // cycles (K2f: it overlaps with nothing): a wave in one of the dependent phases -- assembly, partial-system sums, the
+    // cooperative elimination with its four serial pivots per panel, update, lift -- used to queue behind the other
+    // workgroup's MFMA stream with every short instruction of its chain.  Those phases run at priority 3, the MFMA passes
+    // at 0: the chain gets the port when it is ready, the MFMA stream fills the gaps.  LSPG 1.73e7 -> 1.83e7, Galerkin
+    // 1.78e7 -> 1.87e7 (B = 4096, same box); raising it around the elimination alone gave half of that.
+    __builtin_amdgcn_s_setprio(3);
     for (int slot = blockIdx.x; slot < a.B; slot += gridDim.x) {
         const int smp = a.order ? a.order[slot] : slot;
         if (PIV && !a.force_pivoted && a.info[smp] != BG_INFO_NEEDS_PIVOTING) continue;      // workgroup-uniform
@@ -208,8 +215,10 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
                 lap(0);
                 // ---- projection on the matrix cores -----------------------------------------------------------------
                 // as many passes over the rows as the accumulator budget of this instantiation demands (mfma_passes)
+                __builtin_amdgcn_s_setprio(0);
                 if constexpr (!skip(1))
                     mfma_passes<S, NB, GAL, RW, NRED, kAccBudget>(frag, halo, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
+                __builtin_amdgcn_s_setprio(3);
                 __syncthreads();
                 lap(1);
                 // ---- reduced solve: load own columns (sum of the four waves' partials), eliminate ----------------
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
                 } else {
                     bool tripped;
                     xout = coop_gj_solve<NB, GAL, !skip(2), NRED>(s_red, s_m, s_diag, s_y, s_bad, w, lane, r, tripped);
+
                     if (!kTiming && tripped) aborted = true;
                 }
                 lap(2);
