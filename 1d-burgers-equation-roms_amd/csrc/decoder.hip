@@ -305,6 +305,9 @@ __global__ __launch_bounds__(256, 2) void decode_mlp_kernel(const uint16_t* __re
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __syncthreads();
+    // the store phase of one workgroup goes ahead of the other's MLP phase (bulk VALU + MFMA work) on the shared SIMDs: the
+    // stores it feeds are what the kernel waits for (0.572 -> 0.548 ms per 1024 samples)
+    __builtin_amdgcn_s_setprio(3);
     decode_tiles<KB>(Um, s_q, LD, stage, out, N, Nt, C, c0, lane, w);
 }
 
