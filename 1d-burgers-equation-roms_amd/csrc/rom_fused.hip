@@ -63,13 +63,17 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
     __shared__ double s_g[NPAD];                 // M u^n + dt F of the current time step
     __shared__ double s_h[NPAD];                 // hfs: h_e (f(gp1) + f(gp2)) per element
     __shared__ double s_fdt[NPAD];               // dt F
-    __shared__ double s_coef[NPAD][4];
+    constexpr int CW = GAL ? 4 : 6;              // coefficients per row the projection reads: lo, di, up, R / the pentadiagonal form's six
+    __shared__ __attribute__((aligned(16))) double s_coef[NPAD][CW];
 #ifndef BG_ACC_BUDGET
 #define BG_ACC_BUDGET (((256 - 2 * S * NB - 56) / 2) < 24 ? ((256 - 2 * S * NB - 56) / 2) : 24)
 #endif
     // accumulators a pass may keep live: what 256 registers leave beside the 2 S NB fragment registers and ~56 others (measured at r = 40, N = 512: 16 ... 24 accumulators run alike, 30 spill into the MFMA loop and lose 25 %)
 #ifndef BG_ACC_BUDGET_LSPG
-#define BG_ACC_BUDGET_LSPG (((256 - 2 * S * NB - 48) / 2) < 24 ? ((256 - 2 * S * NB - 48) / 2) : 24)   // LSPG keeps fewer operands live: 24 (measured 20: 1.64e7, 24 / 28: 1.68e7, 30: 1.59e7)
+    // LSPG in the pentadiagonal form (mfma_pass, PENTA): a pass over the column blocks cb0 .. cb1 keeps cb1 - cb0 + 1 operands
+    // Z live next to its accumulators.  Measured at r = 40, N = 512 (B = 4096): 12: 2.16e7, 15 / 16: 2.17e7, 18 / 20: 2.20e7
+    // (four passes: 15 + 13 + 17 + 20 accumulators, 56 B of scratch), 21: 2.13e7, 24: 2.10e7 (three passes, 136 B)
+#define BG_ACC_BUDGET_LSPG (((256 - 2 * S * NB - 48) / 2) < 20 ? ((256 - 2 * S * NB - 48) / 2) : 20)
 #endif
     constexpr int kAccBudget = PIV ? 64 : (GAL ? (BG_ACC_BUDGET) : (BG_ACC_BUDGET_LSPG));
 #ifndef BG_NRED
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
     constexpr int NRED = BG_NRED;
     __shared__ double s_red[NRED][RW][RW + 4];   // per wave pair {w, w + 2}:  Ar | [br, W^T u (Galerkin), 0, 0]
     __shared__ double s_wtu[4][RW];              // per-wave  W^T u (LSPG)
-    __shared__ double s_edge[2][NB][4][4];       // Phi rows just below / above each WAVE's 16 S rows, per column block and t
+    __shared__ double s_edge[2][2][NB][4][4];    // the two Phi rows just below / above each WAVE's 16 S rows, per column block and t
     __shared__ double s_m[2][4][64];             // multipliers of the current / next panel
     __shared__ double s_diag[RW], s_y[RW];       // what the elimination leaves: diagonal and right-hand side
     __shared__ double s_q[RW];
@@ -103,13 +107,19 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
             const int i = rowbase + s;
             frag[c][s] = (i < N && col < r) ? a.Phi[(size_t)i * r + col] : 0.0;
         }
-        if ((lane >> 2) == 0) {                  // the row below this wave's first row (inside a wave: HaloLanes)
-            const int il = rowbase - 1;
-            s_edge[0][c][w][t] = (il >= 0 && il < N && col < r) ? a.Phi[(size_t)il * r + col] : 0.0;
+        if ((lane >> 2) == 0) {                  // the rows below this wave's first row (inside a wave: HaloLanes)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int il = rowbase - 1 - d;
+                s_edge[0][d][c][w][t] = (il >= 0 && il < N && col < r) ? a.Phi[(size_t)il * r + col] : 0.0;
+            }
         }
         if ((lane >> 2) == 15) {
-            const int ih = rowbase + S;
-            s_edge[1][c][w][t] = (ih < N && col < r) ? a.Phi[(size_t)ih * r + col] : 0.0;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int ih = rowbase + S + d;
+                s_edge[1][d][c][w][t] = (ih < N && col < r) ? a.Phi[(size_t)ih * r + col] : 0.0;
+            }
         }
     }
     if (tid < 4) s_u[tid < 2 ? tid : NPAD + tid] = 0.0;      // halos [0], [1], [NPAD+2], [NPAD+3]
@@ -212,12 +222,46 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
                     s_coef[i][0] = lo; s_coef[i][1] = di; s_coef[i][2] = up; s_coef[i][3] = R;
                 }
                 __syncthreads();
+                if constexpr (!GAL) {
+                    // LSPG in the pentadiagonal form (mfma_pass, PENTA): row i of A^T A and (A^T R)_i from the rows i - 1, i, i + 1
+                    // of A (J_k = [lo_k, di_k, up_k] at the columns k - 1, k, k + 1):
+                    //   (A^T A)_{i,i-2} = up_{i-1} lo_{i-1}            (A^T A)_{i,i-1} = up_{i-1} di_{i-1} + di_i lo_i
+                    //   (A^T A)_{i,i}   = up_{i-1}^2 + di_i^2 + lo_{i+1}^2
+                    //   (A^T A)_{i,i+1} = di_i up_i + lo_{i+1} di_{i+1}    (A^T A)_{i,i+2} = lo_{i+1} up_{i+1}
+                    //   (A^T R)_i       = up_{i-1} R_{i-1} + di_i R_i + lo_{i+1} R_{i+1}
+                    // read by every thread for its own rows, a barrier, then written over the same rows.
+                    double pen[NPAD / 256][6];
+#pragma unroll
+                    for (int ii = 0; ii < NPAD / 256; ++ii) {
+                        const int i = tid + 256 * ii;
+                        const bool hm = i > 0, hp = i + 1 < NPAD;
+                        const double lm = hm ? s_coef[hm ? i - 1 : 0][0] : 0.0, dm = hm ? s_coef[hm ? i - 1 : 0][1] : 0.0;
+                        const double um = hm ? s_coef[hm ? i - 1 : 0][2] : 0.0, Rm = hm ? s_coef[hm ? i - 1 : 0][3] : 0.0;
+                        const double l0 = s_coef[i][0], d0 = s_coef[i][1], u0c = s_coef[i][2], R0 = s_coef[i][3];
+                        const double lp = hp ? s_coef[hp ? i + 1 : 0][0] : 0.0, dp = hp ? s_coef[hp ? i + 1 : 0][1] : 0.0;
+                        const double upp = hp ? s_coef[hp ? i + 1 : 0][2] : 0.0, Rp = hp ? s_coef[hp ? i + 1 : 0][3] : 0.0;
+                        pen[ii][0] = um * lm;
+                        pen[ii][1] = __builtin_fma(um, dm, d0 * l0);
+                        pen[ii][2] = __builtin_fma(lp, lp, __builtin_fma(d0, d0, um * um));
+                        pen[ii][3] = __builtin_fma(lp, dp, d0 * u0c);
+                        pen[ii][4] = lp * upp;
+                        pen[ii][5] = __builtin_fma(lp, Rp, __builtin_fma(d0, R0, um * Rm));
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int ii = 0; ii < NPAD / 256; ++ii) {
+                        const int i = tid + 256 * ii;
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) s_coef[i][e] = pen[ii][e];
+                    }
+                    __syncthreads();
+                }
                 lap(0);
                 // ---- projection on the matrix cores -----------------------------------------------------------------
                 // as many passes over the rows as the accumulator budget of this instantiation demands (mfma_passes)
                 __builtin_amdgcn_s_setprio(0);
                 if constexpr (!skip(1))
-                    mfma_passes<S, NB, GAL, RW, NRED, kAccBudget>(frag, halo, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
+                    mfma_passes<S, NB, true, RW, NRED, kAccBudget, 0, !GAL, CW>(frag, halo, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
                 __builtin_amdgcn_s_setprio(3);
                 __syncthreads();
                 lap(1);
@@ -244,10 +288,7 @@ __global__ __launch_bounds__(256, PIV ? 1 : 2) void rom_fused_kernel(RomRunArgs 
                 lap(2);
                 // ---- q = Phi^T u_k + dq, err = |dq| / |q|  (:770-776) ---------------------------------------------
                 double wtu = 0.0;
-                if (lane < r) {
-                    if constexpr (GAL) wtu = entry(lane, RW + 1);
-                    else wtu = (s_wtu[0][lane] + s_wtu[1][lane]) + (s_wtu[2][lane] + s_wtu[3][lane]);
-                }
+                if (lane < r) wtu = entry(lane, RW + 1);        // Phi^T u: the second column of the extra block (both forms)
                 const double dq = (lane < r) ? xout : 0.0;
                 const double qn = (lane < r) ? wtu + dq : 0.0;
                 double nd, nq;

@@ -49,32 +49,48 @@ struct HaloTable {
     const double (*tab)[NB][256];
     int tid;
     template <int S>
-    __device__ __forceinline__ double operator()(int side, int c, const double (&)[NB][S]) const { return tab[side][c][tid]; }
+    __device__ __forceinline__ double operator()(int side, int c, const double (&)[NB][S], int = 0) const { return tab[side][c][tid]; }
 };
 
 template <int NB>
 struct HaloLanes {
-    const double (*edge)[NB][4][4];      // [side][c][wave][t]: the rows just outside each wave's 16 S rows
+    const double (*edge)[2][NB][4][4];   // [side][depth][c][wave][t]: the two rows just outside each wave's 16 S rows
     int w, t, lane;
+    // depth 0: the row next to this lane's block (rowbase - 1 / rowbase + S), depth 1: one further out (the pentadiagonal form)
     template <int S>
-    __device__ __forceinline__ double operator()(int side, int c, const double (&frag)[NB][S]) const
+    __device__ __forceinline__ double operator()(int side, int c, const double (&frag)[NB][S], int depth = 0) const
     {
-        const double mine = side == 0 ? frag[c][S - 1] : frag[c][0];
+        const double mine = side == 0 ? frag[c][S - 1 - depth] : frag[c][depth];
         const int src = side == 0 ? lane - 4 : lane + 4;
         const double nb = from_lane_rot(mine, (src & 63) << 2);
         const bool outside = side == 0 ? lane < 4 : lane >= 60;
-        return outside ? edge[side][c][w][t] : nb;
+        return outside ? edge[side][depth][c][w][t] : nb;
     }
 };
 
-template <int S, int NB, bool GAL, int CA0, int CA1, bool LAST, int RW, int NRED = 4, class Halo>
+// PENTA (with GAL = true): the LSPG system in its pentadiagonal form, Ar = Phi^T (A^T A Phi), br = Phi^T (A^T R).  The caller
+// hands in the five coefficients of row i of A^T A and w_i = (A^T R)_i (s_coef[i][0..5]); the pass is the Galerkin pass --
+// A operands are the basis fragments themselves, every B operand Z = (A^T A) Phi is formed once -- restricted to the block
+// pairs ca <= cb (the system is symmetric: the reader mirrors).  Against the (A Phi)^T (A Phi) form: 65 instead of 75 matrix
+// instructions per row step, 10 operand formations instead of 24 per iteration, three passes instead of four at 24
+// accumulators, and the register profile of the Galerkin kernel (the Y^T Y form kept nine fragment doubles in scratch).
+template <int NB, bool GAL, bool PENTA>
+constexpr int pass_rows(int c0, int c1)
+{
+    int n = 0;
+    for (int c = c0; c < c1; ++c) n += PENTA ? c + 1 : (GAL ? NB : NB - c + 1);
+    return n;
+}
+
+template <int S, int NB, bool GAL, int CA0, int CA1, bool LAST, int RW, int NRED = 4, bool PENTA = false, int CW = 4, class Halo>
 __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const Halo& halo,
-                                          const double (*__restrict__ s_coef)[4], const double* __restrict__ s_u,
+                                          const double (*__restrict__ s_coef)[CW], const double* __restrict__ s_u,
                                           int rowbase, int t, int w, int lane,
                                           double (*__restrict__ s_red)[RW][RW + 4], double (*__restrict__ s_wtu)[RW])
 {
     static_assert(NRED == 4 || NRED == 2, "four per-wave partial systems, or two shared by wave pairs");
-    constexpr int NROW = GAL ? (CA1 - CA0) * NB : (CA1 - CA0) * (2 * NB - CA0 - CA1 + 1) / 2 + (CA1 - CA0);
+    static_assert(!PENTA || (GAL && CW >= 6), "the pentadiagonal form runs the Galerkin pass on six coefficients per row");
+    constexpr int NROW = pass_rows<NB, GAL, PENTA>(CA0, CA1);
     constexpr int NACC = NROW + (LAST ? NB : 0);
     double acc[NACC];
 #pragma unroll
@@ -96,17 +112,39 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const Hal
         const int i = rowbase + ss;
         const double lo = s_coef[i][0], di = s_coef[i][1], up = s_coef[i][2], R = s_coef[i][3];
         const double ui = s_u[i + 2];
-        const double X = (t == 0) ? R : ((t == 1) ? ui : 0.0);
+        double X;
+        if constexpr (PENTA) X = (t == 0) ? s_coef[i][5] : ((t == 1) ? ui : 0.0);      // [A^T R, u, 0, 0]
+        else X = (t == 0) ? R : ((t == 1) ? ui : 0.0);
         if constexpr (GAL) {
             double Y[CA1 - CA0];
+            if constexpr (PENTA) {
+                // Z = (A^T A Phi) row: coefficients of the rows i - 2 .. i + 2 in s_coef[i][0..4] (lo, di, up, R above hold 0..3)
+                const double p2 = s_coef[i][4];
 #pragma unroll
-            for (int c = CA0; c < CA1; ++c) Y[c - CA0] = form_y(ss, c, lo, di, up);
+                for (int c = CA0; c < CA1; ++c) {
+                    const double fm2 = (s >= 2) ? frag[c][s >= 2 ? s - 2 : 0] : halo(0, c, frag, 1 - s);
+                    const double fm1 = (s >= 1) ? frag[c][s >= 1 ? s - 1 : 0] : halo(0, c, frag, 0);
+                    const double fp1 = (s <= S - 2) ? frag[c][s <= S - 2 ? s + 1 : 0] : halo(1, c, frag, 0);
+                    const double fp2 = (s <= S - 3) ? frag[c][s <= S - 3 ? s + 2 : 0] : halo(1, c, frag, s - (S - 2));
+                    double z = lo * fm2;
+                    z = __builtin_fma(di, fm1, z);
+                    z = __builtin_fma(up, frag[c][s], z);
+                    z = __builtin_fma(R, fp1, z);
+                    Y[c - CA0] = __builtin_fma(p2, fp2, z);
+                }
+            } else {
+#pragma unroll
+                for (int c = CA0; c < CA1; ++c) Y[c - CA0] = form_y(ss, c, lo, di, up);
+            }
             int p = 0;
 #pragma unroll
             for (int ca = 0; ca < NB; ++ca) {
 #pragma unroll
-                for (int cb = CA0; cb < CA1; ++cb, ++p)
+                for (int cb = CA0; cb < CA1; ++cb) {
+                    if (PENTA && ca > cb) continue;
                     acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(frag[ca][s], Y[cb - CA0], acc[p], 0, 0, 0);
+                    ++p;
+                }
             }
             if constexpr (LAST) {
 #pragma unroll
@@ -175,7 +213,11 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const Hal
 #pragma unroll
             for (int ca = 0; ca < NB; ++ca) {
 #pragma unroll
-                for (int cb = CA0; cb < CA1; ++cb, ++p) f(p, ca, cb);
+                for (int cb = CA0; cb < CA1; ++cb) {
+                    if (PENTA && ca > cb) continue;
+                    f(p, ca, cb);
+                    ++p;
+                }
             }
             if constexpr (LAST) {
 #pragma unroll
@@ -210,32 +252,30 @@ __device__ __forceinline__ void mfma_pass(const double (&frag)[NB][S], const Hal
 // 2 S NB of them hold the fragments, so the (NB + 1) NB (Galerkin) / NB (NB + 1) / 2 + 2 NB (LSPG) accumulators are
 // produced in as many passes as a budget of BUDGET accumulators demands.  Galerkin passes split the column blocks cb of
 // the B side, LSPG passes the row blocks ca; the last pass carries the [R, u] / Phi^T u extras.
-template <int NB, bool GAL>
+template <int NB, bool GAL, bool PENTA = false>
 constexpr int pass_acc_count(int c0, int c1)
 {
-    int n = 0;
-    for (int c = c0; c < c1; ++c) n += GAL ? NB : NB - c + 1;
-    return n + (c1 == NB ? NB : 0);
+    return pass_rows<NB, GAL, PENTA>(c0, c1) + (c1 == NB ? NB : 0);
 }
 
-template <int NB, bool GAL, int BUDGET>
+template <int NB, bool GAL, int BUDGET, bool PENTA = false>
 constexpr int pass_end(int c0)
 {
     int c1 = c0 + 1;
-    while (c1 < NB && pass_acc_count<NB, GAL>(c0, c1 + 1) <= BUDGET) ++c1;
+    while (c1 < NB && pass_acc_count<NB, GAL, PENTA>(c0, c1 + 1) <= BUDGET) ++c1;
     return c1;
 }
 
-template <int S, int NB, bool GAL, int RW, int NRED, int BUDGET, int C0 = 0, class Halo>
+template <int S, int NB, bool GAL, int RW, int NRED, int BUDGET, int C0 = 0, bool PENTA = false, int CW = 4, class Halo>
 __device__ __forceinline__ void mfma_passes(const double (&frag)[NB][S], const Halo& halo,
-                                            const double (*__restrict__ s_coef)[4], const double* __restrict__ s_u,
+                                            const double (*__restrict__ s_coef)[CW], const double* __restrict__ s_u,
                                             int rowbase, int t, int w, int lane,
                                             double (*__restrict__ s_red)[RW][RW + 4], double (*__restrict__ s_wtu)[RW])
 {
-    constexpr int C1 = pass_end<NB, GAL, BUDGET>(C0);
-    mfma_pass<S, NB, GAL, C0, C1, C1 == NB, RW, NRED>(frag, halo, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
+    constexpr int C1 = pass_end<NB, GAL, BUDGET, PENTA>(C0);
+    mfma_pass<S, NB, GAL, C0, C1, C1 == NB, RW, NRED, PENTA, CW>(frag, halo, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
     if constexpr (C1 < NB)
-        mfma_passes<S, NB, GAL, RW, NRED, BUDGET, C1>(frag, halo, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
+        mfma_passes<S, NB, GAL, RW, NRED, BUDGET, C1, PENTA, CW>(frag, halo, s_coef, s_u, rowbase, t, w, lane, s_red, s_wtu);
 }
 
 // ---- cooperative unpivoted elimination (see the file header) ----------------------------------------------------
